@@ -1,0 +1,358 @@
+"""TEST INFRASTRUCTURE -- CPU oracle for the D3PM codec-token sampler.  Not product code.
+
+A functional (state-dict in, tensors out) PyTorch-CPU restatement of the reference's sampling
+path, op for op, including its quirks.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product (tts-with-diffusion-model_amd/) never does.
+
+Parity status: PINNED.  tests/golden/make_golden.py imports the reference itself
+(/root/reference/vall_e/vall_e/ar_discrete.py, via tests/golden/ref_harness.py) in the build
+container, runs both on the same weights / inputs / noise and commits the reference's outputs under
+tests/golden/; tests/test_oracle_golden.py re-checks this oracle against those vectors on every
+run, and tests/test_oracle_vs_reference.py checks bit-equality live whenever /root/reference exists.
+
+Third-party arithmetic (not under /root/reference): torch's `multi_head_attention_forward`,
+`layer_norm`, `linear`, `softmax`, `gelu`, `silu` -- called here through the same public
+functional entry points the reference's nn.Modules reach (torch pinned by the image: 2.10.0) --
+and timm's `Mlp` (unpinned upstream; published definition fc1 -> act -> fc2).
+
+Reference map (file:line under /root/reference/vall_e/vall_e/):
+    cosine_betas          ar_discrete.py:257,286-304
+    dense_tables          ar_discrete.py:268-277,315-334
+    scalar_tables         closed form of the above, proven equal in tests
+    sinusoid_pe           ar_discrete.py:41-92 (incl. the x.shape[0] quirk at :89)
+    prompt_embedding      base.py:244-274   (one-hot einsum == sum of level embeddings)
+    cond_encoder          ar_discrete.py:216-230,738-746
+    dit_block             ar_discrete.py:98-161
+    denoiser_logits       ar_discrete.py:752-776
+    posterior_logits_*    ar_discrete.py:337-400
+    p_sample_*            ar_discrete.py:401-420
+    q_sample              ar_discrete.py:467-502
+    generate              ar_discrete.py:696-780
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import philox
+
+K_CLASSES = 1025
+MASK_ID = K_CLASSES // 2
+EPS = 1.0e-6
+
+
+@dataclasses.dataclass(frozen=True)
+class Shape:
+    """Mirror of the product's D3PMConfig (kept separate: the oracle must not import the product)."""
+    d_model: int = 32
+    n_heads: int = 16
+    n_layers: int = 8
+    canvas: int = 448
+    n_frames: int = 350
+    s_text: int = 50
+    s_prompt: int = 398
+    timesteps: int = 100
+    n_levels: int = 8
+    cond_heads: int = 16
+    cond_layers: int = 2
+
+    @staticmethod
+    def of(cfg) -> "Shape":
+        return Shape(**{f.name: getattr(cfg, f.name) for f in dataclasses.fields(Shape)})
+
+
+# --------------------------------------------------------------------------------------------
+# D3PM schedule and transition tables
+# --------------------------------------------------------------------------------------------
+def cosine_betas(timesteps: int, s: float = 0.008) -> torch.Tensor:
+    """fp16 betas, length timesteps+1.  The reference calls its schedule with `timesteps+1`
+    points and the schedule itself adds one more, so the grid is linspace(0, n+1, n+1), n=timesteps+1."""
+    n = timesteps + 1
+    grid = np.linspace(0, n + 1, n + 1)
+    acp = np.cos(((grid / (n + 1)) + s) / (1 + s) * np.pi * 0.5) ** 2
+    acp = acp / acp[0]
+    betas = np.clip(1 - acp[1:] / acp[:-1], 0, 0.999)
+    return torch.from_numpy(betas).to(torch.float16)
+
+
+def dense_tables(betas: torch.Tensor, timesteps: int, K: int = K_CLASSES, mask_id: int = MASK_ID):
+    """The reference's three [timesteps, K, K] fp16 tables: one-step Q_t, cumulative Qbar_t
+    (fp16 tensordot chain) and the transposed one-step tables.  630 MB at K=1025, T=100."""
+    steps = []
+    for t in range(timesteps):
+        b = betas[t].numpy()                       # fp16 scalar; arithmetic below is fp64
+        m = np.diag(np.full((K,), 1.0 - b, dtype=np.float64))
+        m[:, mask_id] += b
+        steps.append(torch.from_numpy(m))
+    onestep = torch.stack(steps, 0).to(torch.float16)
+    cum = [onestep[0]]
+    for t in range(1, timesteps):
+        cum.append(torch.tensordot(cum[-1], onestep[t], dims=[[1], [0]]))
+    qbar = torch.stack(cum, 0).to(torch.float16)
+    return onestep, qbar, onestep.transpose(1, 2).to(torch.float16)
+
+
+def _rn16(x: float) -> np.float16:
+    return np.float32(x).astype(np.float16)
+
+
+def scalar_tables(betas: torch.Tensor, timesteps: int):
+    """Closed form of dense_tables: every table is d*I + c*1*e_M^T with row M = e_M, so each
+    timestep needs (d_t, c_t) one-step and (dbar_t, cbar_t) cumulative -- fp16 scalars, the
+    cumulative ones by the fp32-accumulate / round-to-fp16 recurrence the fp16 tensordot performs.
+    Returns float16 numpy arrays (d, c, dbar, cbar), each [timesteps]."""
+    b = betas.numpy().astype(np.float16)
+    d = np.zeros(timesteps, np.float16)
+    c = np.zeros(timesteps, np.float16)
+    dbar = np.zeros(timesteps, np.float16)
+    cbar = np.zeros(timesteps, np.float16)
+    for t in range(timesteps):
+        d[t] = np.float16(1.0 - np.float64(b[t]))          # fp64 (1-beta) -> fp16, as np.diag(...).to(half)
+        c[t] = b[t]
+        if t == 0:
+            dbar[t], cbar[t] = d[t], c[t]
+        else:
+            dbar[t] = _rn16(np.float32(dbar[t - 1]) * np.float32(d[t]))
+            cbar[t] = _rn16(np.float32(dbar[t - 1]) * np.float32(c[t]) + np.float32(cbar[t - 1]))
+    return d, c, dbar, cbar
+
+
+# --------------------------------------------------------------------------------------------
+# Conditioning side (runs once per utterance)
+# --------------------------------------------------------------------------------------------
+def sinusoid_omega(d_model: int) -> torch.Tensor:
+    half = d_model // 2
+    e = torch.arange(half, dtype=torch.float16) / half
+    return torch.exp(-math.log(1e4) * e)                    # fp16 arithmetic throughout
+
+
+def sinusoid_pe(n: int, d_model: int, dtype: torch.dtype) -> torch.Tensor:
+    """[n, d] table [sin | cos] (concatenated, not interleaved).  omega is *computed* in fp16 and
+    then follows the module dtype (.half() keeps it, .float() widens the fp16 values)."""
+    omega = sinusoid_omega(d_model).to(dtype)
+    ang = omega[None, :] * torch.arange(n)[:, None]
+    return torch.cat([ang.sin(), ang.cos()], dim=-1)
+
+
+def prompt_embedding(w: torch.Tensor, codes: torch.Tensor) -> torch.Tensor:
+    """codes [S, n_levels] int64, w [n_levels, K, d] -> [S, d]; same one-hot contraction as upstream."""
+    oh = F.one_hot(codes, num_classes=w.shape[1])
+    oh = F.pad(oh, (0, 0, 0, w.shape[0] - oh.shape[1])).to(w)
+    return torch.einsum("l k d, n l k -> n d", w, oh)
+
+
+def _mha(sd, prefix, q, k, v, heads, need_weights):
+    return F.multi_head_attention_forward(
+        q, k, v, q.shape[-1], heads,
+        sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"], None, None, False, 0.0,
+        sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"],
+        training=False, key_padding_mask=None, need_weights=need_weights, attn_mask=None,
+        average_attn_weights=True)[0]
+
+
+def _ln(sd, prefix, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def _lin(sd, prefix, x):
+    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def cond_encoder(sd, name: str, x: torch.Tensor, shape: Shape) -> torch.Tensor:
+    """x [S, d] (unbatched) -> [S, d].  Two post-norm encoder layers (ReLU, eps 1e-5,
+    need_weights=False) then fc1 -> SiLU -> fc2; dropout is identity (eval mode)."""
+    for j in range(shape.cond_layers):
+        p = f"{name}.0.layers.{j}"
+        x = _ln(sd, p + ".norm1", x + _mha(sd, p + ".self_attn", x, x, x, shape.cond_heads, False), 1e-5)
+        x = _ln(sd, p + ".norm2", x + _lin(sd, p + ".linear2", F.relu(_lin(sd, p + ".linear1", x))), 1e-5)
+    return _lin(sd, f"{name}.1.fc2", F.silu(_lin(sd, f"{name}.1.fc1", x)))
+
+
+def pad_rows(x: torch.Tensor, n: int) -> torch.Tensor:
+    """Zero-pad or truncate dim 0 to n (ar_discrete.py:711-735)."""
+    if x.shape[0] >= n:
+        return x[:n]
+    pad = [0, 0] * (x.dim() - 1) + [0, n - x.shape[0]]
+    return F.pad(x, pad)
+
+
+def encode_conditions(sd, shape: Shape, text: torch.Tensor, prompt: torch.Tensor):
+    """One utterance: text int64[<=s_text], prompt int64[*, n_levels] ->
+    (cond_prompt [s_prompt, d], cond_text [s_text, d]) in the dtype of sd."""
+    dtype = sd["final.weight"].dtype
+    d = shape.d_model
+    text = pad_rows(text, shape.s_text)
+    prompt = pad_rows(prompt, shape.s_prompt)
+    # prompt: true per-position PE (2-D input to add_pe -> x.shape[0] == s_prompt)
+    cp = prompt_embedding(sd["proms_emb.weight"], prompt) + sinusoid_pe(shape.s_prompt, d, dtype)
+    # text: add_pe sees [1, s_text, d] -> get_pe(1): PE of position 0 on every phoneme
+    ct = F.embedding(text, sd["text_emb.weight"]) + sinusoid_pe(1, d, dtype)
+    return cond_encoder(sd, "encoder2", cp, shape), cond_encoder(sd, "encodertext", ct, shape)
+
+
+# --------------------------------------------------------------------------------------------
+# Denoiser
+# --------------------------------------------------------------------------------------------
+def dit_block(sd, i: int, x, cond_prompt, cond_text, t_emb, mask, shape: Shape):
+    """x [1,T,d], cond_* [1,S,d], t_emb [1,d], mask bool [T] -> [1,T,d]."""
+    p = f"blocks.{i}"
+    H = shape.n_heads
+    m = mask[None, :, None]
+    x = (x * m).transpose(0, 1)                                # [T,1,d] sequence-first
+    h = _ln(sd, p + ".norm1", x, 1e-6)
+    x = x + _mha(sd, p + ".attn", h, h, h, H, True)            # all T rows are keys (no padding mask)
+    kt = cond_text.transpose(0, 1)
+    kp = cond_prompt.transpose(0, 1)
+    a_text = _mha(sd, p + ".cross_attn", _ln(sd, p + ".norm2", x, 1e-6), kt, kt, H, True)
+    a_prom = _mha(sd, p + ".cross_attn", _ln(sd, p + ".norm22", x, 1e-6), kp, kp, H, True)  # same weights
+    x = x + a_text + a_prom
+    film = _lin(sd, p + ".timestep_fc", t_emb)
+    d = shape.d_model
+    scale, shift = film[:, :d][None], film[:, d:][None]
+    h = _ln(sd, p + ".norm3", x, 1e-6) * (1 + scale) + shift
+    x = x + _lin(sd, p + ".mlp.fc2", F.gelu(_lin(sd, p + ".mlp.fc1", h)))
+    return x.transpose(0, 1) * m
+
+
+def denoiser_hidden(sd, shape: Shape, x_t, t: int, cond_prompt, cond_text, mask):
+    """x_t int [T] -> hidden [1,T,d] after all blocks (before the final mask+linear)."""
+    t_emb = F.embedding(torch.tensor([t]), sd["time_emb.weight"])
+    x = F.embedding(x_t.long(), sd["resps_emb.weight"])[None]
+    for i in range(shape.n_layers):
+        x = dit_block(sd, i, x, cond_prompt[None], cond_text[None], t_emb, mask, shape)
+    return x
+
+
+def denoiser_logits(sd, shape: Shape, x_t, t: int, cond_prompt, cond_text, mask):
+    """-> x0-logits [T, K] in the dtype of sd."""
+    x = denoiser_hidden(sd, shape, x_t, t, cond_prompt, cond_text, mask)
+    return _lin(sd, "final", x * mask[None, :, None])[0]
+
+
+# --------------------------------------------------------------------------------------------
+# Posterior / sampling.  Everything here is fp16, as in the reference (tables are hard-cast).
+# --------------------------------------------------------------------------------------------
+def posterior_logits_dense(logits16, x_t, t: int, onestep_T, qbar):
+    """Faithful: two [T,K]x[K,K] fp16 matmuls against the dense tables. logits16 [T,K] fp16."""
+    K = logits16.shape[-1]
+    fact1 = torch.matmul(F.one_hot(x_t.long(), K).to(torch.float16), onestep_T[t])
+    fact2 = torch.matmul(F.softmax(logits16, dim=-1), qbar[t - 1 if t > 0 else 0])
+    out = torch.log(fact1 + EPS) + torch.log(fact2 + EPS)
+    return logits16 if t == 0 else out
+
+
+def posterior_logits_closed(logits16, x_t, t: int, tabs, mask_id: int = MASK_ID):
+    """Same numbers from the 4 scalars per step (no K x K table).  The only order-dependent
+    reduction is fact2[:, mask_id] (a K-term fp32 sum the dense matmul performs in BLAS order)."""
+    if t == 0:
+        return logits16
+    d, c, dbar, cbar = tabs
+    K = logits16.shape[-1]
+    x_t = x_t.long()
+    dt, ct = torch.tensor(d[t]), torch.tensor(c[t])
+    db, cb = torch.tensor(dbar[t - 1]), torch.tensor(cbar[t - 1])
+    is_m = (x_t == mask_id)[:, None]
+    cols = torch.arange(K)[None, :]
+    f1_masked = torch.where(cols == mask_id, torch.tensor(1.0, dtype=torch.float16), ct)
+    f1_plain = torch.where(cols == x_t[:, None], dt, torch.tensor(0.0, dtype=torch.float16))
+    fact1 = torch.where(is_m, f1_masked, f1_plain).to(torch.float16)
+    p = F.softmax(logits16, dim=-1)
+    fact2 = (p.float() * db.float()).to(torch.float16)
+    pm = p.float().clone()
+    p_mask = pm[:, mask_id].clone()
+    pm[:, mask_id] = 0
+    fact2[:, mask_id] = (pm.sum(-1) * cb.float() + p_mask).to(torch.float16)
+    return torch.log(fact1 + EPS) + torch.log(fact2 + EPS)
+
+
+def gumbel_argmax(post16, uniform32, t: int):
+    """argmax(posterior(fp16) + [t != 0] * -log(-log(clamp(u)))) with the fp32 add of the reference."""
+    u = torch.clamp(uniform32, min=torch.finfo(torch.float32).tiny, max=1.0)
+    g = -torch.log(-torch.log(u))
+    nz = torch.tensor(int(t != 0))
+    return torch.argmax(post16 + nz * g, dim=-1)
+
+
+def q_sample(x0, t: int, tabs, uniform32, mask, mask_id: int = MASK_ID):
+    """Forward noising: argmax(log(onehot(x0) @ Qbar_t + eps) + gumbel) * mask, closed form of the
+    row of Qbar_t (d̄ at x0, c̄ at mask_id, row mask_id = e_mask)."""
+    _, _, dbar, cbar = tabs
+    K = uniform32.shape[-1]
+    x0 = x0.long()
+    cols = torch.arange(K)[None, :]
+    row = torch.zeros(x0.shape[0], K, dtype=torch.float16)
+    row = torch.where(cols == mask_id, torch.tensor(cbar[t]), row)
+    row = torch.where(cols == x0[:, None], torch.tensor(dbar[t]), row)
+    row = torch.where((x0 == mask_id)[:, None], (cols == mask_id).to(torch.float16), row)
+    logits = torch.log(row + EPS)
+    return gumbel_argmax(logits, uniform32, 1) * mask
+
+
+# --------------------------------------------------------------------------------------------
+# Full reverse process
+# --------------------------------------------------------------------------------------------
+NoiseFn = Callable[[int, int], torch.Tensor]     # (t, utterance_index) -> fp32 [T, K]
+
+
+def philox_noise(seed: int, canvas: int, K: int = K_CLASSES) -> NoiseFn:
+    def fn(t: int, utt: int) -> torch.Tensor:
+        return torch.from_numpy(philox.uniform_batch(seed, t, utt, 1, canvas, K)[0])
+    return fn
+
+
+class Oracle:
+    """Holds weights (a reference-layout state dict, any float dtype) and the D3PM tables."""
+
+    def __init__(self, sd: dict, shape: Shape, dense: bool = False):
+        self.sd = sd
+        self.shape = shape
+        self.dtype = sd["final.weight"].dtype
+        self.betas = cosine_betas(shape.timesteps)
+        self.tabs = scalar_tables(self.betas, shape.timesteps)
+        self.dense = dense_tables(self.betas, shape.timesteps) if dense else None
+
+    def canvas_init(self):
+        s = self.shape
+        x = torch.zeros(s.canvas, dtype=torch.int64)
+        x[: s.n_frames] = MASK_ID
+        return x, x != 0                                         # mask is fixed for the whole loop
+
+    def conditions(self, text, prompt):
+        return encode_conditions(self.sd, self.shape, text, prompt)
+
+    def logits(self, x_t, t, cond_prompt, cond_text, mask):
+        return denoiser_logits(self.sd, self.shape, x_t, t, cond_prompt, cond_text, mask)
+
+    def posterior(self, logits, x_t, t):
+        z = logits.to(torch.float16)
+        if self.dense is not None:
+            return posterior_logits_dense(z, x_t, t, self.dense[2], self.dense[1])
+        return posterior_logits_closed(z, x_t, t, self.tabs)
+
+    def step(self, x_t, t, cond_prompt, cond_text, mask, uniform32, greedy=False):
+        post = self.posterior(self.logits(x_t, t, cond_prompt, cond_text, mask), x_t, t)
+        if greedy:
+            return torch.argmax(post, dim=-1)
+        return gumbel_argmax(post, uniform32, t)
+
+    def generate(self, text, prompt, noise: Optional[NoiseFn], utt: int = 0, greedy: bool = False,
+                 t_start: Optional[int] = None, t_stop: int = 0, trace: Optional[list] = None):
+        """One utterance; returns int64 [canvas] (untrimmed, like the reference).  The loop runs
+        t = t_start .. t_stop+1; t_start defaults to timesteps-1 (the reference reads
+        `self.timesteps` at call time, so a shorter run re-uses the long schedule's tables)."""
+        with torch.no_grad():
+            x, mask = self.canvas_init()
+            cp, ct = self.conditions(text, prompt)
+            if t_start is None:
+                t_start = self.shape.timesteps - 1
+            for t in range(t_start, t_stop, -1):
+                u = None if greedy else noise(t, utt)
+                x = self.step(x, t, cp, ct, mask, u, greedy)
+                if trace is not None:
+                    trace.append(x.clone())
+            return x
