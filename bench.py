@@ -1,0 +1,171 @@
+"""bench.py -- EnCodec codec-tokens/sec of the 100-step D3PM sampler on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full reverse process (condition encoders + 99 denoise/sample iterations) over this
+rank's batch of utterances, inputs resident in HBM.  Workload at every N: BASELINE.json configs[1]
+("LibriTTS"): d=512, 8 heads, 6 blocks, 750 live frames on a 768 canvas,
+50 phoneme + 225 prompt keys, 32 utterances per GPU (weak scaling), synthetic random-init weights.
+Tokens counted are the live level-0 codec frames the D3PM produces (n_q = 1, as upstream).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "tts-with-diffusion-model_amd"), ROOT]
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}    # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="libritts", choices=["libritts", "native", "vctk"])
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--cpu-steps", type=int, default=8, help="diffusion iterations timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-latency", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_flops_per_step(cfg, batch):
+    """F_tok = L(32 d^2 + 4 T d + 4 d (S_t+S_p)) + 2 d K per canvas row and iteration."""
+    d, T = cfg.d_model, cfg.canvas
+    f_tok = cfg.n_layers * (32 * d * d + 4 * T * d + 4 * d * (cfg.s_text + cfg.s_prompt)) + 2 * d * cfg.n_classes
+    return float(f_tok) * batch * T * (cfg.timesteps - 1)
+
+
+def cpu_baseline(cfg, sd32, texts, proms, n_iters):
+    """The oracle (op-for-op port of the reference sampler incl. its dense 1025x1025 table matmuls
+    and need_weights=True attention), fp16 like the reference, on all host cores, for `n_iters`
+    diffusion iterations of ONE utterance; extrapolated to the full 99-iteration utterance."""
+    from oracle import d3pm_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    orc = O.Oracle({k: v.half() for k, v in sd32.items()}, O.Shape.of(cfg), dense=True)
+    noise = O.philox_noise(123, cfg.canvas)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        x, mask = orc.canvas_init()
+        cp, ct = orc.conditions(texts[0], proms[0])
+        t_cond = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for t in range(cfg.timesteps - 1, cfg.timesteps - 1 - n_iters, -1):
+            x = orc.step(x, t, cp, ct, mask, noise(t, 0))
+        t_iter = (time.perf_counter() - t0) / n_iters
+    per_utt = t_cond + t_iter * (cfg.timesteps - 1)
+    return {"value": cfg.n_frames / per_utt, "unit": "codec_tokens/s", "cores": cores, "kind": "port",
+            "sample": f"1 utterance, {n_iters} of {cfg.timesteps - 1} diffusion iterations timed "
+                      f"({t_iter * 1e3:.0f} ms each) + condition encoders ({t_cond * 1e3:.0f} ms), extrapolated; "
+                      "fp16 eager PyTorch CPU, dense transition tables"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__ as g
+    g.build()
+    from vall_e.vall_e import AR, _hip, dp, synth
+
+    cfg = {"libritts": synth.D3PMConfig.libritts, "native": synth.D3PMConfig.native,
+           "vctk": synth.D3PMConfig.vctk_long_prompt}[args.config]()
+    batch = args.batch or (32 if args.config != "native" else 1)
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    sd32 = synth.make_state_dict(cfg, 0)
+    model = AR.from_config(cfg)
+    model.load_state_dict(sd32)
+    model = model.to(dtype).to(dev)
+    texts, proms = synth.make_inputs(cfg, batch * world, 1)
+    texts = [t.to(dev) for t in texts]
+    proms = [p.to(dev) for p in proms]
+
+    def step(i):
+        return dp.generate_audio_dp(model, texts, proms, seed=123 + i)       # shards by rank, all-gathers ids
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    iters = cfg.timesteps - 1
+    _hip.prof_enable(_hip.K_GEMM, args.steps * iters * (cfg.n_layers * 9 + 1) + 64)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    launches, gemm_ms, gemm_flops, _ = _hip.prof_read()
+    _hip.prof_disable()
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tmax.item()
+    assert out.shape == (batch * world, cfg.canvas)
+
+    tokens = batch * world * cfg.n_frames * args.steps
+    ms_per_step = elapsed / args.steps * 1e3
+    result = {
+        "metric": "EnCodec codec-tokens/sec (whole node), 100-step D3PM",
+        "value": tokens / elapsed, "unit": "codec_tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.config}: d={cfg.d_model} H={cfg.n_heads} L={cfg.n_layers} "
+                               f"T={cfg.n_frames}/{cfg.canvas} S_text={cfg.s_text} S_prompt={cfg.s_prompt} "
+                               f"{iters} diffusion iterations, n_q=1",
+                   "utterances_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}"},
+    }
+    if rank == 0:
+        key = args.dtype
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        result["roofline"] = {"bound": "mfma", "kernel": "linear (all DiT GEMM launches of the timed region)",
+                              "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[key], "unit": "TFLOP/s",
+                              "frac": achieved / MFMA_PEAK_TFLOPS[key], "traffic": None,
+                              "launches": launches, "avg_launch_us": gemm_ms * 1e3 / max(launches, 1),
+                              "gemm_share_of_step": gemm_ms / (ms_per_step * args.steps)}
+        whole = algorithmic_flops_per_step(cfg, batch) / (ms_per_step * 1e-3) / 1e12
+        result["whole_step_tflops"] = whole
+        if not args.no_latency:
+            lat = []
+            for i in range(5):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                model.generate_audio(texts[:1], proms[:1], seed=i)
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e3)
+            result["p50_utterance_latency_ms"] = statistics.median(lat[1:])
+        if world == 1 and args.cpu_steps > 0:
+            cpu_texts, cpu_proms = synth.make_inputs(cfg, 1, 1)
+            result["cpu_baseline"] = cpu_baseline(cfg, sd32, cpu_texts, cpu_proms, args.cpu_steps)
+            result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

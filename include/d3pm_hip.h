@@ -1,0 +1,175 @@
+/* d3pm_hip.h -- C ABI of the MI355X (gfx950) D3PM codec-token sampler.
+ *
+ * The upstream project has no FFI layer: its boundary is the Python module API
+ * (vall_e.vall_e.get_model / AR.generate_audio).  This header is the C-ABI that
+ * sits *below* that Python surface; each entry point names the reference statements it replaces
+ * (paths relative to /root/reference/vall_e/vall_e/).
+ *
+ * Conventions
+ *   - every pointer marked "device" is HBM memory owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); nothing is allocated, freed or synchronised inside the library;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*), so calls are capturable
+ *     in a hipGraph and ordered with the caller's other work on that stream;
+ *   - return value: 0 = ok, <0 = error (see D3PM_E_*); nothing throws across the ABI;
+ *     d3pm_last_error() gives a thread-local message for the last failure;
+ *   - `dtype` selects storage *and* arithmetic of the denoiser: F32 (exact-f32 FMA path, the
+ *     1e-3 logits-parity mode), F16 (the only dtype the reference sampler runs in) or BF16.
+ *     Accumulation is always fp32; every op output is rounded to `dtype` where the reference's
+ *     eager model rounds.  The posterior/sampling arithmetic is fp16 in every mode, as upstream
+ *     (its tables are hard-cast to fp16, ar_discrete.py:257-277).
+ *   - token ids are int32, row-major [batch][canvas]; activations are [batch*canvas][d_model].
+ */
+#ifndef D3PM_HIP_H
+#define D3PM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3PM_ABI_VERSION 1
+
+enum { D3PM_F32 = 0, D3PM_F16 = 1, D3PM_BF16 = 2 };
+
+enum {
+  D3PM_OK = 0,
+  D3PM_E_ARG = -1,        /* null pointer / inconsistent sizes                     */
+  D3PM_E_WORKSPACE = -2,  /* workspace smaller than d3pm_workspace_bytes()         */
+  D3PM_E_HIP = -3,        /* a HIP runtime call or kernel launch failed            */
+  D3PM_E_SHAPE = -4       /* shape not supported by any kernel in this build       */
+};
+
+/* flags for d3pm_sample_loop / d3pm_denoise_step */
+enum {
+  D3PM_FLAG_GREEDY = 1,        /* argmax of the posterior without Gumbel noise   */
+  D3PM_FLAG_FORCE_GENERIC = 2, /* never take the MFMA kernels (cross-check / debugging)          */
+  D3PM_FLAG_UNFUSED_SAMPLE = 4 /* materialise [B,T,K] logits and sample in a second kernel       */
+};
+
+typedef struct d3pm_shape {
+  int32_t d_model;    /* 32 upstream (ar_discrete.py:208); 512 asked by get_model (__init__.py:26) */
+  int32_t n_heads;    /* 16 upstream (ar_discrete.py:238)                                          */
+  int32_t n_layers;   /* 8 upstream  (ar_discrete.py:238)                                          */
+  int32_t canvas;     /* frames per utterance the denoiser sees, 448 upstream (:704)               */
+  int32_t s_text;     /* phoneme keys, 50 upstream (:714)                                          */
+  int32_t s_prompt;   /* prompt keys, 398 upstream (:726)                                          */
+  int32_t n_classes;  /* 1025 (:255)                                                               */
+  int32_t mask_id;    /* absorbing id 512 (:332)                                                   */
+  int32_t timesteps;  /* 100 (:207); the loop runs t = timesteps-1 .. 1 (:750)                     */
+  int32_t dtype;      /* D3PM_F32 / D3PM_F16 / D3PM_BF16                                           */
+} d3pm_shape;
+
+/* One DiT block's parameters (ar_discrete.py:103-124), device pointers, elements of `dtype`,
+ * torch layouts: Linear weight [out][in]; MultiheadAttention in_proj [3d][d] (q|k|v rows).
+ * cross_attn2.* is dead upstream (the prompt attention re-uses cross_attn, :142) and not passed. */
+typedef struct d3pm_block_weights {
+  const void *norm1_w, *norm1_b;          /* [d]               LayerNorm eps 1e-6 (:108)  */
+  const void *attn_in_w, *attn_in_b;      /* [3d][d], [3d]     self-attention (:109)      */
+  const void *attn_out_w, *attn_out_b;    /* [d][d], [d]                                  */
+  const void *norm2_w, *norm2_b;          /* text-query LN (:112)                         */
+  const void *norm22_w, *norm22_b;        /* prompt-query LN (:117)                       */
+  const void *cross_in_w, *cross_in_b;    /* [3d][d], [3d]     cross_attn (:113)          */
+  const void *cross_out_w, *cross_out_b;  /* [d][d], [d]                                  */
+  const void *norm3_w, *norm3_b;          /* (:121)                                       */
+  const void *fc1_w, *fc1_b;              /* [4d][d], [4d]     timm Mlp (:123)            */
+  const void *fc2_w, *fc2_b;              /* [d][4d], [d]                                 */
+  const void *tfc_w, *tfc_b;              /* [2d][d], [2d]     timestep_fc (:124)         */
+} d3pm_block_weights;
+
+typedef struct d3pm_weights {
+  const void *resps_emb;                  /* [n_classes][d]  (:212)                       */
+  const void *time_emb;                   /* [timesteps+1][d] (:213)                      */
+  const void *final_w, *final_b;          /* [n_classes][d], [n_classes] (:240)           */
+  const d3pm_block_weights *blocks;       /* HOST array of n_layers entries               */
+} d3pm_weights;
+
+/* fp16 bit patterns of the absorbing-state schedule, HOST arrays.
+ * betas[timesteps+1]; d,c,dbar,cbar[timesteps]:  Q_t = d_t I + c_t 1 e_M^T,  Qbar_t likewise. */
+typedef struct d3pm_schedule {
+  int32_t timesteps;
+  const uint16_t *d, *c, *dbar, *cbar;
+} d3pm_schedule;
+
+int d3pm_abi_version(void);
+const char *d3pm_last_error(void);
+
+/* Replaces AR.cosine_beta_schedule + the 3 x [T,1025,1025] fp16 table build
+ * (ar_discrete.py:257,268-277,286-304,315-334) by the 4 fp16 scalars per step they reduce to
+ * (SURVEY.md §8a a14).  Pure host arithmetic; all outputs are HOST arrays of fp16 bit patterns. */
+int d3pm_schedule_build(int timesteps, uint16_t *betas /*[timesteps+1]*/, uint16_t *d, uint16_t *c,
+                        uint16_t *dbar, uint16_t *cbar /*[timesteps] each*/);
+
+/* Bytes of device scratch the step/loop entry points need for `batch` utterances. */
+size_t d3pm_workspace_bytes(const d3pm_shape *shape, int batch);
+
+/* Step-invariant precomputation ----------------------------------------------------------- */
+
+/* film[t][layer][2d] = timestep_fc_layer(time_emb[t])  (ar_discrete.py:145,752) for every t:
+ * the FiLM scale/shift depends on weights and t only, so it is tabulated once per weight set. */
+int d3pm_film_table(const d3pm_shape *shape, const d3pm_weights *w, void *film /*device*/,
+                    void *stream);
+
+/* K/V projections of the step-invariant conditions with cross_attn's k/v rows
+ * (the `k`/`v` halves of F.multi_head_attention_forward's in-projection for the calls at
+ * ar_discrete.py:138,142).  cond_* are device [batch][S][d]; kv_* receive [n_layers][batch][S][2d]. */
+int d3pm_cond_kv(const d3pm_shape *shape, const d3pm_weights *w, int batch, const void *cond_text,
+                 const void *cond_prompt, void *kv_text, void *kv_prompt, void *stream);
+
+/* One denoiser evaluation --------------------------------------------------------------------
+ * Replaces the loop body at ar_discrete.py:752-776: resps_emb gather, n_layers x DiTBlock.forward
+ * (:126-161, incl. torch's multi_head_attention_forward need_weights branch and timm Mlp), final
+ * Linear on the masked hidden state.  x_t device int32 [batch][canvas]; frame_mask device uint8
+ * [canvas]; logits_out device [batch*canvas][n_classes] of `dtype`; hidden_out optional
+ * [batch*canvas][d] (state after the last block, before the final mask) or NULL;
+ * only_layers >= 0 stops after that many blocks (block-level parity tests). */
+int d3pm_denoise_step(const d3pm_shape *shape, const d3pm_weights *w, int batch, const int32_t *x_t,
+                      const uint8_t *frame_mask, int t, const void *film, const void *kv_text,
+                      const void *kv_prompt, void *workspace, size_t workspace_bytes,
+                      void *logits_out, void *hidden_out, int only_layers, uint32_t flags,
+                      void *stream);
+
+/* Replaces AR.p_sample / q_posterior_logits / _at / _at_onehot (ar_discrete.py:337-420):
+ * fp16 softmax of the x0-logits, closed-form fact1/fact2, log+log in fp16, fp32 Gumbel add from
+ * the Philox stream (seed, row = (utt0+b)*canvas+frame, t), first-index argmax.
+ * logits device [batch*canvas][n_classes] of logits_dtype; posterior_out optional device fp16
+ * bit patterns [batch*canvas][n_classes] or NULL. */
+int d3pm_posterior_sample(const d3pm_shape *shape, int batch, const void *logits, int logits_dtype,
+                          const int32_t *x_t, int32_t *x_next, int t, const d3pm_schedule *sched,
+                          uint64_t seed, uint32_t utt0, uint32_t flags, uint16_t *posterior_out,
+                          void *stream);
+
+/* Replaces the whole reverse process of AR.generate_audio after the condition encoders
+ * (ar_discrete.py:748-780): for t = t_start .. t_stop+1: denoise step + posterior sample.
+ * x device int32 [batch][canvas], in: x_T, out: x_{t_stop}.  trace optional device int32
+ * [t_start-t_stop][batch][canvas] receiving x after every step, or NULL. */
+int d3pm_sample_loop(const d3pm_shape *shape, const d3pm_weights *w, int batch, int32_t *x,
+                     const uint8_t *frame_mask, int t_start, int t_stop, const void *film,
+                     const void *kv_text, const void *kv_prompt, const d3pm_schedule *sched,
+                     uint64_t seed, uint32_t utt0, uint32_t flags, void *workspace,
+                     size_t workspace_bytes, int32_t *trace, void *stream);
+
+/* Replaces AR.q_sample / q_probs (ar_discrete.py:467-502): forward noising of x0 at step t with
+ * Philox stream 1.  x0, x_out device int32 [batch][canvas]. */
+int d3pm_q_sample(const d3pm_shape *shape, int batch, const int32_t *x0, int32_t *x_out,
+                  const uint8_t *frame_mask, int t, const d3pm_schedule *sched, uint64_t seed,
+                  uint32_t utt0, void *stream);
+
+/* The raw uniform stream the two samplers consume (what the reference draws with torch.rand,
+ * ar_discrete.py:402,480): out device fp32 [rows][n_classes] for global rows row0.. at step t. */
+int d3pm_uniform(uint64_t seed, int t, uint32_t row0, int rows, int n_classes, int stream_id,
+                 float *out, void *stream);
+
+/* Timing hooks for bench.py's roofline object: when enabled, every launch of the kernel class
+ * `kclass` (D3PM_K_*) inside d3pm_sample_loop is bracketed by a hipEvent pair on `stream`;
+ * d3pm_prof_read synchronises those events and returns launch count and total milliseconds. */
+enum { D3PM_K_GEMM = 0, D3PM_K_ATTN = 1, D3PM_K_SAMPLE = 2, D3PM_K_LN = 3, D3PM_K_COUNT = 4 };
+int d3pm_prof_enable(int kclass, int max_events);
+int d3pm_prof_read(int *launches, double *total_ms, double *flops, double *bytes);
+int d3pm_prof_disable(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3PM_HIP_H */

@@ -1,0 +1,128 @@
+"""The CPU oracle against the fixtures the *reference itself* produced (tests/golden/make_golden.py).
+
+Integer / table / sampler outputs must be bit-exact everywhere.  Bit-exact equality of transformer
+activations additionally needs the CPU the fixtures were generated on (BLAS accumulation order);
+elsewhere a 2-ulp fp16 / 1e-5 fp32 tolerance applies.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import same_platform_as_golden
+from oracle import d3pm_oracle as O
+from oracle import philox
+from util import bits, f16, load, native_setup, ulp16_diff
+
+
+def test_schedule_scalars_match_reference_tables():
+    g = load("tables_t100.npz")
+    assert bool(g["structured"])
+    betas = O.cosine_betas(100)
+    assert np.array_equal(bits(betas), g["betas"])
+    for mine, name in zip(O.scalar_tables(betas, 100), ("d", "c", "dbar", "cbar")):
+        assert np.array_equal(mine.view(np.uint16), g[name]), name
+    assert g["eps16"][0] == bits(torch.tensor([1e-6], dtype=torch.float16))[0]
+
+
+def test_dense_tables_have_closed_form_structure():
+    """Independent of the fixture: rebuild the reference-style dense tables for a short schedule and
+    check d*I + c*1e_M^T with row M = e_M against the scalar recurrence."""
+    T, K, M = 12, 65, 32
+    betas = O.cosine_betas(T)
+    one, qbar, one_t = O.dense_tables(betas, T, K, M)
+    d, c, db, cb = O.scalar_tables(betas, T)
+    for t in range(T):
+        for tab, dd, cc in ((one[t], d[t], c[t]), (qbar[t], db[t], cb[t])):
+            exp = torch.zeros(K, K, dtype=torch.float16)
+            exp.fill_diagonal_(float(dd))
+            exp[:, M] = float(cc)
+            exp[M, :] = 0
+            exp[M, M] = 1
+            assert torch.equal(tab, exp), t
+        assert torch.equal(one_t[t], one[t].T)
+
+
+def test_posterior_closed_form_equals_dense_matmul():
+    torch.manual_seed(3)
+    T = 100
+    orc_tabs = O.scalar_tables(O.cosine_betas(T), T)
+    dense = O.dense_tables(O.cosine_betas(T), T)
+    logits = (torch.randn(64, 1025) * 1.5).half()
+    x_t = torch.randint(0, 1025, (64,))
+    x_t[::2] = 512
+    for t in (1, 2, 40, 99):
+        a = O.posterior_logits_dense(logits, x_t, t, dense[2], dense[1])
+        b = O.posterior_logits_closed(logits, x_t, t, orc_tabs)
+        assert torch.equal(a, b), t
+    assert torch.equal(O.posterior_logits_closed(logits, x_t, 0, orc_tabs), logits)
+
+
+def test_sampler_on_reference_logits():
+    g = load("native_step.npz")
+    cfg, _, _, _, orc = native_setup()
+    logits = f16(g["logits_full_f16"])
+    x_t = torch.from_numpy(g["x_t"].astype(np.int64))
+    t = int(g["t"])
+    post = orc.posterior(logits, x_t, t)
+    assert np.array_equal(bits(post[g["rows"]]), g["posterior_rows_f16"])
+    u = torch.from_numpy(philox.uniform_batch(123, t, 0, 1, cfg.canvas)[0])
+    assert np.array_equal(O.gumbel_argmax(post, u, t).numpy(), g["x_next_seed123"].astype(np.int64))
+    uq = torch.from_numpy(philox.uniform_batch(123, t, 0, 1, cfg.canvas, stream=philox.STREAM_Q_SAMPLE)[0])
+    mask = torch.zeros(cfg.canvas, dtype=torch.bool)
+    mask[: cfg.n_frames] = True
+    assert np.array_equal(O.q_sample(x_t, t, orc.tabs, uq, mask).numpy(), g["q_sample_seed123"].astype(np.int64))
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("f16", torch.float16)])
+def test_denoiser_tensors(tag, dtype):
+    g = load("native_step.npz")
+    cfg, _, texts, proms, orc = native_setup(dtype)
+    exact = same_platform_as_golden()
+    conv = (lambda a: torch.from_numpy(a)) if dtype == torch.float32 else f16
+
+    def close(mine, ref, what):
+        ref = conv(ref)
+        if exact:
+            assert torch.equal(mine, ref), what
+        elif dtype == torch.float32:
+            assert (mine - ref).abs().max() < 1e-4, what
+        else:
+            assert ulp16_diff(mine, ref).max() <= 4, what
+
+    with torch.no_grad():
+        cp, ct = orc.conditions(texts[0], proms[0])
+        close(cp, g[f"cond_prompt_{tag}"], "cond_prompt")
+        close(ct, g[f"cond_text_{tag}"], "cond_text")
+        x_t = torch.from_numpy(g["x_t"].astype(np.int64))
+        mask = torch.zeros(cfg.canvas, dtype=torch.bool)
+        mask[: cfg.n_frames] = True
+        t = int(g["t"])
+        x0 = conv(g[f"block0_in_{tag}"])
+        temb = orc.sd["time_emb.weight"][t][None]
+        y0 = O.dit_block(orc.sd, 0, x0[None], cp[None], ct[None], temb, mask, orc.shape)[0]
+        close(y0, g[f"block0_out_{tag}"], "block0_out")
+        close(O.denoiser_hidden(orc.sd, orc.shape, x_t, t, cp, ct, mask)[0], g[f"hidden_{tag}"], "hidden")
+        close(orc.logits(x_t, t, cp, ct, mask)[g["rows"]], g[f"logits_rows_{tag}"], "logits")
+
+
+def test_plumbing_10_steps_and_greedy():
+    """BASELINE.json configs[0] (10 diffusion steps, CPU) and the degenerate greedy mode."""
+    g = load("native_loop.npz")
+    cfg, sd32, texts, proms, orc = native_setup()
+    y = orc.generate(texts[0], proms[0], O.philox_noise(123, cfg.canvas), t_start=10)
+    if same_platform_as_golden():
+        assert np.array_equal(y.numpy(), g["plumbing10_utt0_seed123"].astype(np.int64))
+    else:
+        assert (y.numpy() == g["plumbing10_utt0_seed123"]).mean() > 0.98
+    # greedy never unmasks with these weights: every live frame stays 512, pad rows stay 0
+    yg = orc.generate(texts[0], proms[0], None, greedy=True, t_start=5)
+    assert (yg[: cfg.n_frames] == 512).all() and np.array_equal(g["greedy"][: cfg.n_frames], np.full(cfg.n_frames, 512))
+
+
+@pytest.mark.skipif(not same_platform_as_golden(), reason="full trajectories are only bit-stable on the fixture CPU")
+def test_full_loop_trajectory_utt1():
+    g = load("native_loop.npz")
+    cfg, sd32, texts, proms, orc = native_setup()
+    tr = []
+    orc.generate(texts[1], proms[1], O.philox_noise(7, cfg.canvas), trace=tr)
+    assert np.array_equal(torch.stack(tr).numpy(), g["traj_utt1_seed7"].astype(np.int64))

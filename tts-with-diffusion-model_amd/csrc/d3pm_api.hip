@@ -1,0 +1,369 @@
+// d3pm_api.hip -- extern "C" entry points (include/d3pm_hip.h) and the per-step launch sequence.
+//
+// One denoiser evaluation = the loop body of AR.generate_audio (ar_discrete.py:752-776):
+//   embed -> n_layers x { LN1, QKV GEMM, self-attention, out GEMM(+res), LN2/LN22, 2 x Q GEMM,
+//   2 x cross-attention against the cached condition K/V, 2 x out GEMM(+res), LN3+FiLM,
+//   fc1 GEMM(+GELU), fc2 GEMM(+res, *mask) } -> final GEMM -> posterior/sample.
+// Nothing here allocates or synchronises; everything is enqueued on the caller's stream.
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "d3pm_kernels.h"
+
+namespace d3pm {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int q_sample_launch(const d3pm_shape*, int, const int32_t*, int32_t*, const uint8_t*, int, const d3pm_schedule*,
+                    uint64_t, uint32_t, hipStream_t);
+int uniform_launch(uint64_t, int, uint32_t, int, int, int, float*, hipStream_t);
+
+// ---- profiling hooks (bench.py roofline object) ----------------------------------------------
+struct Prof {
+  int kclass = -1;
+  std::vector<hipEvent_t> ev;   // pairs
+  int used = 0;
+  double flops = 0, bytes = 0;
+};
+static Prof g_prof;
+
+struct ProfScope {
+  bool on;
+  hipStream_t s;
+  ProfScope(int kclass, hipStream_t st, double flops, double bytes) : s(st) {
+    on = g_prof.kclass == kclass && g_prof.used + 2 <= static_cast<int>(g_prof.ev.size());
+    if (on) {
+      (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+      g_prof.flops += flops;
+      g_prof.bytes += bytes;
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
+      g_prof.used += 2;
+    }
+  }
+};
+
+// ---- kernel-family dispatch ----------------------------------------------------------------
+static int run_linear(int dtype, const LinearArgs& a, uint32_t flags, hipStream_t s) {
+  const size_t es = dtype_size(dtype);
+  ProfScope p(D3PM_K_GEMM, s, 2.0 * a.M * a.N * a.K,
+              es * (static_cast<double>(a.M) * a.K + static_cast<double>(a.N) * a.K + static_cast<double>(a.M) * a.N));
+  if (!(flags & D3PM_FLAG_FORCE_GENERIC) && mfma_linear_supported(dtype, a)) return mfma_linear(dtype, a, s);
+  return generic_linear(dtype, a, s);
+}
+static int run_attention(int dtype, const AttnArgs& a, uint32_t flags, hipStream_t s) {
+  ProfScope p(D3PM_K_ATTN, s, 4.0 * a.B * a.H * a.Tq * static_cast<double>(a.S) * a.hd,
+              dtype_size(dtype) * (2.0 * a.B * a.Tq * a.H * a.hd + 2.0 * a.B * a.S * a.H * a.hd));
+  if (!(flags & D3PM_FLAG_FORCE_GENERIC) && mfma_attention_supported(dtype, a)) return mfma_attention(dtype, a, s);
+  return generic_attention(dtype, a, s);
+}
+static int run_layernorm(int dtype, const LayerNormArgs& a, uint32_t flags, hipStream_t s) {
+  ProfScope p(D3PM_K_LN, s, 0.0, dtype_size(dtype) * static_cast<double>(a.M) * a.d * (a.Y2 ? 3.0 : 2.0));
+  (void)flags;
+  return generic_layernorm(dtype, a, s);
+}
+
+// ---- workspace carve-up ----------------------------------------------------------------------
+struct Workspace {
+  char *x, *h, *h2, *qkv, *att, *att2, *mlp, *logits;
+  size_t total;
+};
+static size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
+  const size_t es = dtype_size(sh.dtype), n = static_cast<size_t>(batch) * sh.canvas, d = sh.d_model;
+  Workspace w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+  w.x = take(n * d * es);
+  w.h = take(n * d * es);
+  w.h2 = take(n * d * es);
+  w.qkv = take(n * 3 * d * es);
+  w.att = take(n * d * es);
+  w.att2 = take(n * d * es);
+  w.mlp = take(n * 4 * d * es);
+  w.logits = take(n * sh.n_classes * es);
+  w.total = off;
+  return w;
+}
+
+static int check_shape(const d3pm_shape* sh, int batch) {
+  D3PM_REQUIRE(sh, D3PM_E_ARG, "null shape");
+  D3PM_REQUIRE(batch > 0 && sh->d_model > 0 && sh->n_heads > 0 && sh->d_model % sh->n_heads == 0 && sh->n_layers > 0 &&
+                   sh->canvas > 0 && sh->s_text > 0 && sh->s_prompt > 0 && sh->n_classes > 1 && sh->mask_id >= 0 &&
+                   sh->mask_id < sh->n_classes && sh->timesteps >= 2,
+               D3PM_E_ARG, "inconsistent d3pm_shape");
+  D3PM_REQUIRE(sh->dtype == D3PM_F32 || sh->dtype == D3PM_F16 || sh->dtype == D3PM_BF16, D3PM_E_ARG, "bad dtype %d",
+               sh->dtype);
+  return D3PM_OK;
+}
+
+#define D3PM_TRY(expr)            \
+  do {                            \
+    int rc_ = (expr);             \
+    if (rc_ != D3PM_OK) return rc_; \
+  } while (0)
+
+static const char* at(const void* p, size_t elems, size_t es) { return static_cast<const char*>(p) + elems * es; }
+static char* at(void* p, size_t elems, size_t es) { return static_cast<char*>(p) + elems * es; }
+
+// hidden state after `layers` blocks is left in ws.x
+static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batch, const int32_t* x_t,
+                           const uint8_t* frame_mask, int t, const void* film, const void* kv_text,
+                           const void* kv_prompt, const Workspace& ws, int layers, uint32_t flags, hipStream_t s) {
+  const int dt = sh.dtype, d = sh.d_model, H = sh.n_heads, hd = d / H, T = sh.canvas;
+  const int n = batch * T;
+  const size_t es = dtype_size(dt);
+  const float scale = static_cast<float>(std::sqrt(1.0 / static_cast<double>(hd)));
+
+  EmbedArgs e;
+  e.tokens = x_t; e.frame_mask = frame_mask; e.canvas = T; e.table = w.resps_emb; e.Y = ws.x;
+  e.M = n; e.d = d; e.n_classes = sh.n_classes;
+  D3PM_TRY(embed_tokens(dt, e, s));
+
+  for (int l = 0; l < layers; ++l) {
+    const d3pm_block_weights& b = w.blocks[l];
+    // ---- self-attention ----
+    LayerNormArgs ln;
+    ln.X = ws.x; ln.Y = ws.h; ln.w = b.norm1_w; ln.b = b.norm1_b; ln.M = n; ln.d = d; ln.eps = 1e-6f;
+    D3PM_TRY(run_layernorm(dt, ln, flags, s));
+    LinearArgs g;
+    g.X = ws.h; g.ldx = d; g.W = b.attn_in_w; g.bias = b.attn_in_b; g.Y = ws.qkv; g.ldy = 3 * d;
+    g.M = n; g.N = 3 * d; g.K = d;
+    D3PM_TRY(run_linear(dt, g, flags, s));
+    AttnArgs a;
+    a.Q = ws.qkv; a.ldq = 3 * d; a.K = at(ws.qkv, d, es); a.V = at(ws.qkv, 2 * d, es); a.ldkv = 3 * d;
+    a.O = ws.att; a.ldo = d; a.B = batch; a.Tq = T; a.S = T; a.H = H; a.hd = hd; a.scale = scale;
+    D3PM_TRY(run_attention(dt, a, flags, s));
+    g = LinearArgs();
+    g.X = ws.att; g.ldx = d; g.W = b.attn_out_w; g.bias = b.attn_out_b; g.Y = ws.x; g.ldy = d;
+    g.R1 = ws.x; g.ldr = d; g.M = n; g.N = d; g.K = d;
+    D3PM_TRY(run_linear(dt, g, flags, s));
+    // ---- cross-attention: text keys with LN2 queries, prompt keys with LN22 queries, SAME weights ----
+    ln = LayerNormArgs();
+    ln.X = ws.x; ln.Y = ws.h; ln.w = b.norm2_w; ln.b = b.norm2_b; ln.Y2 = ws.h2; ln.w2 = b.norm22_w; ln.b2 = b.norm22_b;
+    ln.M = n; ln.d = d; ln.eps = 1e-6f;
+    D3PM_TRY(run_layernorm(dt, ln, flags, s));
+    char* q_text = ws.qkv;
+    char* q_prom = at(ws.qkv, static_cast<size_t>(n) * d, es);
+    for (int which = 0; which < 2; ++which) {
+      g = LinearArgs();
+      g.X = which ? ws.h2 : ws.h; g.ldx = d; g.W = b.cross_in_w; g.bias = b.cross_in_b;
+      g.Y = which ? q_prom : q_text; g.ldy = d; g.M = n; g.N = d; g.K = d;
+      D3PM_TRY(run_linear(dt, g, flags, s));
+    }
+    for (int which = 0; which < 2; ++which) {
+      const int S = which ? sh.s_prompt : sh.s_text;
+      const void* kv = at(which ? kv_prompt : kv_text, static_cast<size_t>(l) * batch * S * 2 * d, es);
+      a = AttnArgs();
+      a.Q = which ? q_prom : q_text; a.ldq = d; a.K = kv; a.V = at(kv, d, es); a.ldkv = 2 * d;
+      a.O = which ? ws.att2 : ws.att; a.ldo = d; a.B = batch; a.Tq = T; a.S = S; a.H = H; a.hd = hd; a.scale = scale;
+      D3PM_TRY(run_attention(dt, a, flags, s));
+    }
+    // o_text -> h (free now); x = (x + o_text) + o_prompt, rounded at each add like the eager sum
+    g = LinearArgs();
+    g.X = ws.att; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.h; g.ldy = d; g.M = n; g.N = d; g.K = d;
+    D3PM_TRY(run_linear(dt, g, flags, s));
+    g = LinearArgs();
+    g.X = ws.att2; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.x; g.ldy = d;
+    g.R1 = ws.x; g.R2 = ws.h; g.ldr = d; g.M = n; g.N = d; g.K = d;
+    D3PM_TRY(run_linear(dt, g, flags, s));
+    // ---- FiLM-modulated MLP ----
+    ln = LayerNormArgs();
+    ln.X = ws.x; ln.Y = ws.h; ln.w = b.norm3_w; ln.b = b.norm3_b; ln.M = n; ln.d = d; ln.eps = 1e-6f;
+    ln.film = at(film, (static_cast<size_t>(t) * sh.n_layers + l) * 2 * d, es);
+    D3PM_TRY(run_layernorm(dt, ln, flags, s));
+    g = LinearArgs();
+    g.X = ws.h; g.ldx = d; g.W = b.fc1_w; g.bias = b.fc1_b; g.Y = ws.mlp; g.ldy = 4 * d; g.M = n; g.N = 4 * d; g.K = d;
+    g.act = ACT_GELU;
+    D3PM_TRY(run_linear(dt, g, flags, s));
+    g = LinearArgs();
+    g.X = ws.mlp; g.ldx = 4 * d; g.W = b.fc2_w; g.bias = b.fc2_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
+    g.row_mask = frame_mask; g.mask_period = T; g.M = n; g.N = d; g.K = 4 * d;
+    D3PM_TRY(run_linear(dt, g, flags, s));
+  }
+  return D3PM_OK;
+}
+
+static int final_logits(const d3pm_shape& sh, const d3pm_weights& w, int batch, const Workspace& ws, void* logits,
+                        uint32_t flags, hipStream_t s) {
+  // x is already multiplied by the frame mask at the end of every block (ar_discrete.py:161,773)
+  LinearArgs g;
+  g.X = ws.x; g.ldx = sh.d_model; g.W = w.final_w; g.bias = w.final_b; g.Y = logits; g.ldy = sh.n_classes;
+  g.M = batch * sh.canvas; g.N = sh.n_classes; g.K = sh.d_model;
+  return run_linear(sh.dtype, g, flags, s);
+}
+
+}  // namespace d3pm
+
+using namespace d3pm;
+
+extern "C" {
+
+int d3pm_abi_version(void) { return D3PM_ABI_VERSION; }
+const char* d3pm_last_error(void) { return g_err; }
+
+size_t d3pm_workspace_bytes(const d3pm_shape* shape, int batch) {
+  if (check_shape(shape, batch) != D3PM_OK) return 0;
+  return carve(*shape, batch, nullptr).total;
+}
+
+int d3pm_film_table(const d3pm_shape* sh, const d3pm_weights* w, void* film, void* stream) {
+  D3PM_TRY(check_shape(sh, 1));
+  D3PM_REQUIRE(w && w->blocks && w->time_emb && film, D3PM_E_ARG, "d3pm_film_table: null pointer");
+  const int d = sh->d_model;
+  for (int l = 0; l < sh->n_layers; ++l) {
+    LinearArgs g;
+    g.X = w->time_emb; g.ldx = d; g.W = w->blocks[l].tfc_w; g.bias = w->blocks[l].tfc_b;
+    g.Y = at(film, static_cast<size_t>(l) * 2 * d, dtype_size(sh->dtype)); g.ldy = sh->n_layers * 2 * d;
+    g.M = sh->timesteps + 1; g.N = 2 * d; g.K = d;
+    D3PM_TRY(generic_linear(sh->dtype, g, static_cast<hipStream_t>(stream)));
+  }
+  return D3PM_OK;
+}
+
+int d3pm_cond_kv(const d3pm_shape* sh, const d3pm_weights* w, int batch, const void* cond_text, const void* cond_prompt,
+                 void* kv_text, void* kv_prompt, void* stream) {
+  D3PM_TRY(check_shape(sh, batch));
+  D3PM_REQUIRE(w && w->blocks && cond_text && cond_prompt && kv_text && kv_prompt, D3PM_E_ARG, "d3pm_cond_kv: null pointer");
+  const int d = sh->d_model;
+  const size_t es = dtype_size(sh->dtype);
+  for (int l = 0; l < sh->n_layers; ++l)
+    for (int which = 0; which < 2; ++which) {
+      const int S = which ? sh->s_prompt : sh->s_text;
+      LinearArgs g;
+      g.X = which ? cond_prompt : cond_text; g.ldx = d;
+      g.W = at(w->blocks[l].cross_in_w, static_cast<size_t>(d) * d, es);   // k|v rows of the packed in-projection
+      g.bias = at(w->blocks[l].cross_in_b, d, es);
+      g.Y = at(which ? kv_prompt : kv_text, static_cast<size_t>(l) * batch * S * 2 * d, es); g.ldy = 2 * d;
+      g.M = batch * S; g.N = 2 * d; g.K = d;
+      D3PM_TRY(run_linear(sh->dtype, g, 0, static_cast<hipStream_t>(stream)));
+    }
+  return D3PM_OK;
+}
+
+int d3pm_denoise_step(const d3pm_shape* sh, const d3pm_weights* w, int batch, const int32_t* x_t,
+                      const uint8_t* frame_mask, int t, const void* film, const void* kv_text, const void* kv_prompt,
+                      void* workspace, size_t workspace_bytes, void* logits_out, void* hidden_out, int only_layers,
+                      uint32_t flags, void* stream) {
+  D3PM_TRY(check_shape(sh, batch));
+  D3PM_REQUIRE(w && w->blocks && x_t && frame_mask && film && kv_text && kv_prompt && workspace, D3PM_E_ARG,
+               "d3pm_denoise_step: null pointer");
+  D3PM_REQUIRE(t >= 0 && t <= sh->timesteps, D3PM_E_ARG, "t=%d outside [0,%d]", t, sh->timesteps);
+  Workspace ws = carve(*sh, batch, static_cast<char*>(workspace));
+  D3PM_REQUIRE(workspace_bytes >= ws.total, D3PM_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int layers = (only_layers >= 0 && only_layers < sh->n_layers) ? only_layers : sh->n_layers;
+  D3PM_TRY(denoiser_blocks(*sh, *w, batch, x_t, frame_mask, t, film, kv_text, kv_prompt, ws, layers, flags, s));
+  if (hidden_out)
+    D3PM_CHECK_HIP(hipMemcpyAsync(hidden_out, ws.x, static_cast<size_t>(batch) * sh->canvas * sh->d_model * dtype_size(sh->dtype),
+                                  hipMemcpyDeviceToDevice, s));
+  if (logits_out) D3PM_TRY(final_logits(*sh, *w, batch, ws, logits_out, flags, s));
+  return D3PM_OK;
+}
+
+int d3pm_posterior_sample(const d3pm_shape* sh, int batch, const void* logits, int logits_dtype, const int32_t* x_t,
+                          int32_t* x_next, int t, const d3pm_schedule* sched, uint64_t seed, uint32_t utt0,
+                          uint32_t flags, uint16_t* posterior_out, void* stream) {
+  D3PM_TRY(check_shape(sh, batch));
+  D3PM_REQUIRE(logits && x_t && x_next && sched && sched->d && sched->c && sched->dbar && sched->cbar, D3PM_E_ARG,
+               "d3pm_posterior_sample: null pointer");
+  D3PM_REQUIRE(t >= 0 && t < sched->timesteps, D3PM_E_ARG, "t=%d outside the schedule", t);
+  SampleArgs a;
+  a.logits = logits; a.logits_dtype = logits_dtype; a.ldl = sh->n_classes; a.x_t = x_t; a.x_next = x_next;
+  a.posterior_out = posterior_out; a.rows = batch * sh->canvas; a.n_classes = sh->n_classes; a.mask_id = sh->mask_id;
+  a.canvas = sh->canvas; a.seed = seed; a.row0 = utt0 * static_cast<uint32_t>(sh->canvas);
+  a.greedy = (flags & D3PM_FLAG_GREEDY) ? 1 : 0; a.pc = make_posterior_consts(sched, t);
+  return posterior_sample(a, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_sample_loop(const d3pm_shape* sh, const d3pm_weights* w, int batch, int32_t* x, const uint8_t* frame_mask,
+                     int t_start, int t_stop, const void* film, const void* kv_text, const void* kv_prompt,
+                     const d3pm_schedule* sched, uint64_t seed, uint32_t utt0, uint32_t flags, void* workspace,
+                     size_t workspace_bytes, int32_t* trace, void* stream) {
+  D3PM_TRY(check_shape(sh, batch));
+  D3PM_REQUIRE(w && w->blocks && x && frame_mask && film && kv_text && kv_prompt && sched && workspace, D3PM_E_ARG,
+               "d3pm_sample_loop: null pointer");
+  D3PM_REQUIRE(t_start < sched->timesteps && t_start <= sh->timesteps && t_stop >= 0 && t_stop <= t_start, D3PM_E_ARG,
+               "bad step range %d..%d", t_start, t_stop);
+  Workspace ws = carve(*sh, batch, static_cast<char*>(workspace));
+  D3PM_REQUIRE(workspace_bytes >= ws.total, D3PM_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rows = batch * sh->canvas;
+  for (int t = t_start; t > t_stop; --t) {
+    D3PM_TRY(denoiser_blocks(*sh, *w, batch, x, frame_mask, t, film, kv_text, kv_prompt, ws, sh->n_layers, flags, s));
+    D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, flags, s));
+    SampleArgs a;
+    a.logits = ws.logits; a.logits_dtype = sh->dtype; a.ldl = sh->n_classes; a.x_t = x; a.x_next = x;
+    a.x_next2 = trace ? trace + static_cast<size_t>(t_start - t) * rows : nullptr;
+    a.rows = rows; a.n_classes = sh->n_classes; a.mask_id = sh->mask_id; a.canvas = sh->canvas; a.seed = seed;
+    a.row0 = utt0 * static_cast<uint32_t>(sh->canvas); a.greedy = (flags & D3PM_FLAG_GREEDY) ? 1 : 0;
+    a.pc = make_posterior_consts(sched, t);
+    {
+      ProfScope p(D3PM_K_SAMPLE, s, 0.0,
+                  static_cast<double>(rows) * (sh->n_classes * dtype_size(sh->dtype) + 8.0));
+      D3PM_TRY(posterior_sample(a, s));
+    }
+  }
+  return D3PM_OK;
+}
+
+int d3pm_q_sample(const d3pm_shape* sh, int batch, const int32_t* x0, int32_t* x_out, const uint8_t* frame_mask, int t,
+                  const d3pm_schedule* sched, uint64_t seed, uint32_t utt0, void* stream) {
+  D3PM_TRY(check_shape(sh, batch));
+  D3PM_REQUIRE(x0 && x_out && frame_mask && sched && sched->dbar && sched->cbar, D3PM_E_ARG, "d3pm_q_sample: null pointer");
+  D3PM_REQUIRE(t >= 0 && t < sched->timesteps, D3PM_E_ARG, "t=%d outside the schedule", t);
+  return q_sample_launch(sh, batch, x0, x_out, frame_mask, t, sched, seed, utt0, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_uniform(uint64_t seed, int t, uint32_t row0, int rows, int n_classes, int stream_id, float* out, void* stream) {
+  D3PM_REQUIRE(out && rows > 0 && n_classes > 0, D3PM_E_ARG, "d3pm_uniform: bad arguments");
+  return uniform_launch(seed, t, row0, rows, n_classes, stream_id, out, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_prof_enable(int kclass, int max_events) {
+  D3PM_REQUIRE(kclass >= 0 && kclass < D3PM_K_COUNT && max_events > 0, D3PM_E_ARG, "d3pm_prof_enable: bad arguments");
+  d3pm_prof_disable();
+  g_prof.ev.resize(static_cast<size_t>(max_events) * 2);
+  for (auto& e : g_prof.ev) D3PM_CHECK_HIP(hipEventCreate(&e));
+  g_prof.kclass = kclass;
+  g_prof.used = 0;
+  g_prof.flops = g_prof.bytes = 0;
+  return D3PM_OK;
+}
+
+int d3pm_prof_read(int* launches, double* total_ms, double* flops, double* bytes) {
+  double ms = 0;
+  for (int i = 0; i + 1 < g_prof.used; i += 2) {
+    D3PM_CHECK_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
+    float m = 0;
+    D3PM_CHECK_HIP(hipEventElapsedTime(&m, g_prof.ev[i], g_prof.ev[i + 1]));
+    ms += m;
+  }
+  if (launches) *launches = g_prof.used / 2;
+  if (total_ms) *total_ms = ms;
+  if (flops) *flops = g_prof.flops;
+  if (bytes) *bytes = g_prof.bytes;
+  g_prof.used = 0;
+  g_prof.flops = g_prof.bytes = 0;
+  return D3PM_OK;
+}
+
+int d3pm_prof_disable(void) {
+  for (auto& e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.kclass = -1;
+  g_prof.used = 0;
+  return D3PM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// d3pm_kernels.h -- host-side launchers of the denoiser kernels (internal to the library).
+// Two families implement the same contracts:
+//   generic  (d3pm_generic.hip)  any shape, f32/f16/bf16, fp32 FMA arithmetic -- parity mode,
+//                                MFMA-hostile shapes (head_dim 2 of the upstream model), cross-check
+//   mfma     (d3pm_mfma_*.hip)   f16/bf16, LDS-tiled MFMA 16x16x32, shapes that tile by 128/64
+#pragma once
+#include "d3pm_common.h"
+
+namespace d3pm {
+
+enum { ACT_NONE = 0, ACT_GELU = 1 };
+
+// Y[M][N] = epilogue(X[M][K] . W[N][K]^T + bias)      (torch.nn.functional.linear layout)
+// epilogue, with rn() = round to the storage dtype exactly where the eager reference rounds:
+//   v = rn(acc + bias); if act: v = rn(gelu_erf(v));
+//   if R1 && R2: v = rn(rn(R1 + R2) + v)  else if R1: v = rn(R1 + v);
+//   if row_mask: v = v * row_mask[row % mask_period]
+struct LinearArgs {
+  const void* X = nullptr; int ldx = 0;
+  const void* W = nullptr;
+  const void* bias = nullptr;
+  void* Y = nullptr; int ldy = 0;
+  const void* R1 = nullptr; const void* R2 = nullptr; int ldr = 0;
+  const uint8_t* row_mask = nullptr; int mask_period = 1;
+  int M = 0, N = 0, K = 0;
+  int act = ACT_NONE;
+};
+
+// O[b][i][h*hd+c] = sum_j P[i][j] V[b][j][h*hd+c],  P = rn(softmax(rn(rn(q*scale) . k)))
+// element (b, row, h, c) of Q lives at Q + (b*Tq+row)*ldq + h*hd + c; K/V likewise with S, ldkv.
+struct AttnArgs {
+  const void* Q = nullptr; int ldq = 0;
+  const void* K = nullptr; const void* V = nullptr; int ldkv = 0;
+  void* O = nullptr; int ldo = 0;
+  int B = 0, Tq = 0, S = 0, H = 0, hd = 0;
+  float scale = 1.f;
+};
+
+// Y = LN(X) * w + b (eps), optionally FiLM: Y = rn(rn(LN * rn(1 + film[c])) + film[d + c])
+// second output (w2/b2/Y2) optional: a second LayerNorm of the same rows (norm2 + norm22).
+struct LayerNormArgs {
+  const void* X = nullptr; void* Y = nullptr;
+  const void* w = nullptr; const void* b = nullptr;
+  const void* w2 = nullptr; const void* b2 = nullptr; void* Y2 = nullptr;
+  const void* film = nullptr;
+  int M = 0, d = 0; float eps = 1e-6f;
+};
+
+struct EmbedArgs {
+  const int32_t* tokens = nullptr; const uint8_t* frame_mask = nullptr; int canvas = 0;
+  const void* table = nullptr; void* Y = nullptr; int M = 0, d = 0, n_classes = 0;
+};
+
+// per-step scalars of the closed-form posterior (host-built from d3pm_schedule)
+struct PosteriorConsts {
+  float log_f1_zero;   // log16(rn16(0 + eps))
+  float log_f1_d;      // log16(rn16(d_t + eps))      x_t != M, j == x_t
+  float log_f1_c;      // log16(rn16(c_t + eps))      x_t == M, j != M
+  float log_f1_one;    // log16(rn16(1 + eps))        x_t == M, j == M
+  float dbar_prev;     // dbar_{t-1}
+  float cbar_prev;     // cbar_{t-1}
+  int t;
+};
+
+struct SampleArgs {
+  const void* logits = nullptr; int logits_dtype = D3PM_F16; int ldl = 0;
+  const int32_t* x_t = nullptr; int32_t* x_next = nullptr; int32_t* x_next2 = nullptr;
+  uint16_t* posterior_out = nullptr;
+  int rows = 0, n_classes = 0, mask_id = 0, canvas = 0;
+  uint64_t seed = 0; uint32_t row0 = 0; int greedy = 0;
+  PosteriorConsts pc{};
+};
+
+int generic_linear(int dtype, const LinearArgs& a, hipStream_t s);
+int generic_attention(int dtype, const AttnArgs& a, hipStream_t s);
+int generic_layernorm(int dtype, const LayerNormArgs& a, hipStream_t s);
+int embed_tokens(int dtype, const EmbedArgs& a, hipStream_t s);
+int posterior_sample(const SampleArgs& a, hipStream_t s);
+
+// MFMA family: return D3PM_E_SHAPE when the shape does not fit (caller falls back to generic)
+bool mfma_linear_supported(int dtype, const LinearArgs& a);
+int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s);
+bool mfma_attention_supported(int dtype, const AttnArgs& a);
+int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s);
+int fast_layernorm(int dtype, const LayerNormArgs& a, hipStream_t s);
+
+PosteriorConsts make_posterior_consts(const d3pm_schedule* sched, int t);
+
+}  // namespace d3pm

@@ -1,0 +1,211 @@
+// d3pm_sample.hip -- D3PM absorbing-state transition / posterior / categorical sampling kernels.
+//
+// Replaces (paths under /root/reference/vall_e/vall_e/):
+//   posterior_sample_rows  AR.p_sample + q_posterior_logits + _at + _at_onehot (ar_discrete.py:337-420)
+//   q_sample_rows          AR.q_sample + q_probs                               (ar_discrete.py:467-502)
+//   uniform_rows           the torch.rand draws at ar_discrete.py:402,480 (Philox stream instead)
+//
+// The reference multiplies one-hot / softmax rows into dense [1025,1025] fp16 tables; every table
+// is d*I + c*1 e_M^T with row M = e_M (proven on the reference's tables in
+// tests/golden/make_golden.py), so per row the work is O(K):
+//     fact1_j = d_t [j==x] (x != M)      |  c_t (j != M), 1 (j == M)        (x == M)
+//     fact2_j = rn16(p_j * dbar_{t-1}) (j != M),  rn16(cbar_{t-1} * sum_{k!=M} p_k + p_M) (j == M)
+//     out_j   = rn16(log16(rn16(fact1_j+eps)) + log16(rn16(fact2_j+eps)))
+//     x_{t-1} = argmax_j fp32(out_j) + gumbel(u_j)
+// with p = rn16(softmax_fp32(rn16 logits)).  All fp16 rounding points of the eager fp16 model are
+// kept; HBM traffic per row is the K logits in and one id out (plus 4 B of x_t).
+//
+// Mapping: one wave per row; lane l owns class groups g = l, l+64, .. (4 consecutive classes per
+// Philox call), i.e. 5 groups x 4 classes = 20 registers of logits for K = 1025.
+#include <cmath>
+
+#include "d3pm_kernels.h"
+
+namespace d3pm {
+namespace {
+
+constexpr int kMaxGroupsPerLane = 5;   // supports n_classes <= 64*5*4 = 1280
+constexpr float kEps = 1.0e-6f;        // self.eps (ar_discrete.py:276), added in fp32 opmath then rounded
+
+template <typename T> __device__ __forceinline__ float load_logit16(const void* base, size_t idx) {
+  return rn16(static_cast<float>(static_cast<const T*>(base)[idx]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void posterior_sample_rows(
+    const T* __restrict__ logits, int ldl, const int32_t* x_t, int32_t* x_next,
+    int32_t* x_next2, uint16_t* __restrict__ post_out, int rows, int K, int mask_id,
+    uint64_t seed, uint32_t row0, int greedy, PosteriorConsts pc) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (row >= rows) return;
+  const T* lr = logits + static_cast<size_t>(row) * ldl;
+  const int groups = (K + 3) >> 2;
+  float z[kMaxGroupsPerLane][4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < kMaxGroupsPerLane; ++i) {
+    int g = lane + i * kWave;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      int j = g * 4 + w;
+      float v = (g < groups && j < K) ? rn16(static_cast<float>(lr[j])) : -INFINITY;
+      z[i][w] = v;
+      mx = fmaxf(mx, v);
+    }
+  }
+  const int x = x_t[row];
+  int best_j = 0;
+  float best_v = -INFINITY;
+  if (pc.t == 0) {
+    // t == 0: model logits are used as they are and no noise is added (ar_discrete.py:407,413)
+#pragma unroll
+    for (int i = 0; i < kMaxGroupsPerLane; ++i)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        int j = (lane + i * kWave) * 4 + w;
+        if (j < K && z[i][w] > best_v) { best_v = z[i][w]; best_j = j; }
+      }
+  } else {
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxGroupsPerLane; ++i)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float e = expf(z[i][w] - mx);   // exp(-inf) = 0 for the padding classes
+        z[i][w] = e;
+        sum += e;
+      }
+    sum = wave_sum(sum);
+    float s_other = 0.f, p_mask = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxGroupsPerLane; ++i)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        int j = (lane + i * kWave) * 4 + w;
+        float p = rn16(z[i][w] / sum);
+        z[i][w] = p;
+        if (j == mask_id) p_mask = p; else s_other += p;
+      }
+    s_other = wave_sum(s_other);
+    p_mask = wave_sum(p_mask);
+    const float f2_mask = rn16(fmaf(s_other, pc.cbar_prev, p_mask));
+    const bool x_is_mask = (x == mask_id);
+#pragma unroll
+    for (int i = 0; i < kMaxGroupsPerLane; ++i) {
+      int g = lane + i * kWave;
+      if (g >= groups) continue;
+      float u[4];
+      if (!greedy) noise4(seed, static_cast<uint32_t>(g), row0 + static_cast<uint32_t>(row),
+                          static_cast<uint32_t>(pc.t), 0u, u);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        int j = g * 4 + w;
+        if (j >= K) continue;
+        float lf1 = x_is_mask ? (j == mask_id ? pc.log_f1_one : pc.log_f1_c)
+                              : (j == x ? pc.log_f1_d : pc.log_f1_zero);
+        float f2 = (j == mask_id) ? f2_mask : rn16(z[i][w] * pc.dbar_prev);
+        float lf2 = rn16(logf(rn16(f2 + kEps)));
+        float out = rn16(lf1 + lf2);
+        if (post_out) post_out[static_cast<size_t>(row) * K + j] = __builtin_bit_cast(uint16_t, static_cast<f16>(out));
+        float v = greedy ? out : out + gumbel(u[w]);
+        if (v > best_v) { best_v = v; best_j = j; }   // ascending j per lane keeps the first maximum
+      }
+    }
+  }
+  wave_argmax(best_v, best_j);
+  if (lane == 0) {
+    x_next[row] = best_j;
+    if (x_next2) x_next2[row] = best_j;
+  }
+}
+
+// forward noising: logits are log16(rn16(row_of_Qbar_t + eps)) with at most three distinct values
+__global__ __launch_bounds__(256) void q_sample_rows(const int32_t* __restrict__ x0, int32_t* __restrict__ out,
+                                                     const uint8_t* __restrict__ frame_mask, int canvas,
+                                                     int rows, int K, int mask_id, uint64_t seed,
+                                                     uint32_t row0, int t, float log_dbar, float log_cbar,
+                                                     float log_zero, float log_one) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (row >= rows) return;
+  const int x = x0[row];
+  const int groups = (K + 3) >> 2;
+  int best_j = 0;
+  float best_v = -INFINITY;
+  for (int g = lane; g < groups; g += kWave) {
+    float u[4];
+    noise4(seed, static_cast<uint32_t>(g), row0 + static_cast<uint32_t>(row), static_cast<uint32_t>(t), 1u, u);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      int j = g * 4 + w;
+      if (j >= K) continue;
+      float l;
+      if (x == mask_id) l = (j == mask_id) ? log_one : log_zero;
+      else l = (j == x) ? log_dbar : (j == mask_id ? log_cbar : log_zero);
+      float v = l + gumbel(u[w]);
+      if (v > best_v) { best_v = v; best_j = j; }
+    }
+  }
+  wave_argmax(best_v, best_j);
+  if (lane == 0) out[row] = frame_mask[row % canvas] ? best_j : 0;
+}
+
+__global__ void uniform_rows(uint64_t seed, int t, uint32_t row0, int rows, int K, int stream_id,
+                             float* __restrict__ out) {
+  const int groups = (K + 3) >> 2;
+  size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<size_t>(rows) * groups) return;
+  int r = static_cast<int>(idx / groups), g = static_cast<int>(idx % groups);
+  float u[4];
+  noise4(seed, static_cast<uint32_t>(g), row0 + static_cast<uint32_t>(r), static_cast<uint32_t>(t),
+         static_cast<uint32_t>(stream_id), u);
+  for (int w = 0; w < 4; ++w)
+    if (g * 4 + w < K) out[static_cast<size_t>(r) * K + g * 4 + w] = u[w];
+}
+
+}  // namespace
+
+float host_h2f(uint16_t h);
+float host_log16(float fact);
+
+int posterior_sample(const SampleArgs& a, hipStream_t s) {
+  D3PM_REQUIRE(a.n_classes <= kWave * kMaxGroupsPerLane * 4, D3PM_E_SHAPE,
+               "posterior_sample supports up to %d classes", kWave * kMaxGroupsPerLane * 4);
+  const int rpb = 4;
+  dim3 grid((a.rows + rpb - 1) / rpb), block(rpb * kWave);
+#define D3PM_PS(T)                                                                                      \
+  posterior_sample_rows<T><<<grid, block, 0, s>>>(static_cast<const T*>(a.logits), a.ldl, a.x_t, a.x_next, \
+                                                  a.x_next2, a.posterior_out, a.rows, a.n_classes,        \
+                                                  a.mask_id, a.seed, a.row0, a.greedy, a.pc)
+  switch (a.logits_dtype) {
+    case D3PM_F32: D3PM_PS(float); break;
+    case D3PM_F16: D3PM_PS(f16); break;
+    case D3PM_BF16: D3PM_PS(bf16); break;
+    default: set_error("unknown logits dtype %d", a.logits_dtype); return D3PM_E_ARG;
+  }
+#undef D3PM_PS
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+int q_sample_launch(const d3pm_shape* sh, int batch, const int32_t* x0, int32_t* out, const uint8_t* frame_mask,
+                    int t, const d3pm_schedule* sched, uint64_t seed, uint32_t utt0, hipStream_t s) {
+  const int rows = batch * sh->canvas, rpb = 4;
+  float ld = host_log16(host_h2f(sched->dbar[t])), lc = host_log16(host_h2f(sched->cbar[t]));
+  q_sample_rows<<<(rows + rpb - 1) / rpb, rpb * kWave, 0, s>>>(x0, out, frame_mask, sh->canvas, rows, sh->n_classes,
+                                                               sh->mask_id, seed, utt0 * sh->canvas, t, ld, lc,
+                                                               host_log16(0.f), host_log16(1.f));
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+int uniform_launch(uint64_t seed, int t, uint32_t row0, int rows, int K, int stream_id, float* out, hipStream_t s) {
+  size_t n = static_cast<size_t>(rows) * ((K + 3) / 4);
+  uniform_rows<<<static_cast<unsigned>((n + 255) / 256), 256, 0, s>>>(seed, t, row0, rows, K, stream_id, out);
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+}  // namespace d3pm

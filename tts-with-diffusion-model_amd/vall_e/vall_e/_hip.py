@@ -1,0 +1,252 @@
+"""ctypes binding of libd3pm_hip.so (C ABI in include/d3pm_hip.h).
+
+There is deliberately no CPU fallback: if the shared library is missing the import of the
+sampler fails loudly (build it with `python -c "import __graft_entry__ as g; g.build()"`).
+PyTorch is used only to own device memory and to provide the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+F32, F16, BF16 = 0, 1, 2
+FLAG_GREEDY, FLAG_FORCE_GENERIC, FLAG_UNFUSED_SAMPLE = 1, 2, 4
+K_GEMM, K_ATTN, K_SAMPLE, K_LN = 0, 1, 2, 3
+
+_DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+LIB_PATH = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "lib",
+                                         "libd3pm_hip.so"))
+
+
+class Shape(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("d_model", "n_heads", "n_layers", "canvas", "s_text", "s_prompt",
+                                         "n_classes", "mask_id", "timesteps", "dtype")]
+
+
+_BLOCK_FIELDS = ("norm1_w", "norm1_b", "attn_in_w", "attn_in_b", "attn_out_w", "attn_out_b", "norm2_w", "norm2_b",
+                 "norm22_w", "norm22_b", "cross_in_w", "cross_in_b", "cross_out_w", "cross_out_b", "norm3_w",
+                 "norm3_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "tfc_w", "tfc_b")
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _BLOCK_FIELDS]
+
+
+class Weights(C.Structure):
+    _fields_ = [("resps_emb", C.c_void_p), ("time_emb", C.c_void_p), ("final_w", C.c_void_p),
+                ("final_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights))]
+
+
+class ScheduleC(C.Structure):
+    _fields_ = [("timesteps", C.c_int32), ("d", C.POINTER(C.c_uint16)), ("c", C.POINTER(C.c_uint16)),
+                ("dbar", C.POINTER(C.c_uint16)), ("cbar", C.POINTER(C.c_uint16))]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/d3pm_hip.h declares
+SIGNATURES = {
+    "d3pm_abi_version": (C.c_int, []),
+    "d3pm_last_error": (C.c_char_p, []),
+    "d3pm_schedule_build": (C.c_int, [C.c_int] + [C.POINTER(C.c_uint16)] * 5),
+    "d3pm_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int]),
+    "d3pm_film_table": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_void_p, C.c_void_p]),
+    "d3pm_cond_kv": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_int] + [C.c_void_p] * 5),
+    "d3pm_denoise_step": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]),
+    "d3pm_posterior_sample": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_uint32,
+                                        C.c_void_p, C.c_void_p]),
+    "d3pm_sample_loop": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ScheduleC), C.c_uint64,
+                                   C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "d3pm_q_sample": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_void_p]),
+    "d3pm_uniform": (C.c_int, [C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "d3pm_prof_enable": (C.c_int, [C.c_int, C.c_int]),
+    "d3pm_prof_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double)]),
+    "d3pm_prof_disable": (C.c_int, []),
+}
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension has not been built "
+                               "(run __graft_entry__.build()); there is no CPU fallback")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.d3pm_abi_version() != 1:
+            raise RuntimeError("libd3pm_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+class D3PMError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise D3PMError(f"{what} failed with code {rc}: {lib().d3pm_last_error().decode()}")
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return _DTYPES[dtype]
+    except KeyError:
+        raise D3PMError(f"unsupported model dtype {dtype}") from None
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Schedule:
+    """Host-side fp16 schedule scalars (d3pm_schedule_build)."""
+
+    def __init__(self, timesteps: int):
+        self.timesteps = timesteps
+        self.betas = np.zeros(timesteps + 1, np.uint16)
+        self.d, self.c, self.dbar, self.cbar = (np.zeros(timesteps, np.uint16) for _ in range(4))
+        p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint16))
+        check(lib().d3pm_schedule_build(timesteps, p(self.betas), p(self.d), p(self.c), p(self.dbar), p(self.cbar)),
+              "d3pm_schedule_build")
+        self.c_struct = ScheduleC(timesteps, p(self.d), p(self.c), p(self.dbar), p(self.cbar))
+
+
+def make_shape(cfg, dtype: torch.dtype) -> Shape:
+    return Shape(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.canvas, cfg.s_text, cfg.s_prompt, cfg.n_classes,
+                 cfg.mask_id, cfg.timesteps, dtype_code(dtype))
+
+
+class DeviceWeights:
+    """Pointer table over tensors that stay owned by the caller (an nn.Module's parameters)."""
+
+    def __init__(self, tensors: dict, n_layers: int):
+        self._keep = []
+
+        def ptr(key):
+            t = tensors[key]
+            if not (t.is_cuda and t.is_contiguous()):
+                raise D3PMError(f"weight {key} must be a contiguous device tensor")
+            self._keep.append(t)
+            return t.data_ptr()
+
+        self.blocks = (BlockWeights * n_layers)()
+        names = {"norm1_w": "norm1.weight", "norm1_b": "norm1.bias", "attn_in_w": "attn.in_proj_weight",
+                 "attn_in_b": "attn.in_proj_bias", "attn_out_w": "attn.out_proj.weight",
+                 "attn_out_b": "attn.out_proj.bias", "norm2_w": "norm2.weight", "norm2_b": "norm2.bias",
+                 "norm22_w": "norm22.weight", "norm22_b": "norm22.bias", "cross_in_w": "cross_attn.in_proj_weight",
+                 "cross_in_b": "cross_attn.in_proj_bias", "cross_out_w": "cross_attn.out_proj.weight",
+                 "cross_out_b": "cross_attn.out_proj.bias", "norm3_w": "norm3.weight", "norm3_b": "norm3.bias",
+                 "fc1_w": "mlp.fc1.weight", "fc1_b": "mlp.fc1.bias", "fc2_w": "mlp.fc2.weight",
+                 "fc2_b": "mlp.fc2.bias", "tfc_w": "timestep_fc.weight", "tfc_b": "timestep_fc.bias"}
+        for i in range(n_layers):
+            for field, key in names.items():
+                setattr(self.blocks[i], field, ptr(f"blocks.{i}.{key}"))
+        self.c_struct = Weights(ptr("resps_emb.weight"), ptr("time_emb.weight"), ptr("final.weight"),
+                                ptr("final.bias"), self.blocks)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Sampler:
+    """Thin object API over the C entry points for one (shape, weights) pair."""
+
+    def __init__(self, cfg, tensors: dict, dtype: torch.dtype, device):
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.shape = make_shape(cfg, dtype)
+        self.weights = DeviceWeights(tensors, cfg.n_layers)
+        self.schedule = Schedule(cfg.timesteps)
+        self._ws = None
+        self.film = torch.empty((cfg.timesteps + 1, cfg.n_layers, 2 * cfg.d_model), dtype=dtype, device=self.device)
+        check(lib().d3pm_film_table(C.byref(self.shape), C.byref(self.weights.c_struct), _p(self.film), stream_ptr()),
+              "d3pm_film_table")
+
+    def workspace(self, batch: int) -> torch.Tensor:
+        need = lib().d3pm_workspace_bytes(C.byref(self.shape), batch)
+        if need == 0:
+            raise D3PMError("d3pm_workspace_bytes: " + lib().d3pm_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def cond_kv(self, cond_text: torch.Tensor, cond_prompt: torch.Tensor):
+        """cond_text [B,S_t,d], cond_prompt [B,S_p,d] -> per-layer K|V tensors [L,B,S,2d]."""
+        cfg, B = self.cfg, cond_text.shape[0]
+        assert cond_text.shape == (B, cfg.s_text, cfg.d_model) and cond_prompt.shape == (B, cfg.s_prompt, cfg.d_model)
+        cond_text, cond_prompt = cond_text.to(self.dtype).contiguous(), cond_prompt.to(self.dtype).contiguous()
+        kv_t = torch.empty((cfg.n_layers, B, cfg.s_text, 2 * cfg.d_model), dtype=self.dtype, device=self.device)
+        kv_p = torch.empty((cfg.n_layers, B, cfg.s_prompt, 2 * cfg.d_model), dtype=self.dtype, device=self.device)
+        check(lib().d3pm_cond_kv(C.byref(self.shape), C.byref(self.weights.c_struct), B, _p(cond_text),
+                                 _p(cond_prompt), _p(kv_t), _p(kv_p), stream_ptr()), "d3pm_cond_kv")
+        return kv_t, kv_p
+
+    def denoise(self, x_t, frame_mask, t, kv_t, kv_p, *, want_logits=True, want_hidden=False, only_layers=-1,
+                flags=0):
+        cfg, B = self.cfg, x_t.shape[0]
+        ws = self.workspace(B)
+        logits = torch.empty((B, cfg.canvas, cfg.n_classes), dtype=self.dtype, device=self.device) if want_logits else None
+        hidden = torch.empty((B, cfg.canvas, cfg.d_model), dtype=self.dtype, device=self.device) if want_hidden else None
+        check(lib().d3pm_denoise_step(C.byref(self.shape), C.byref(self.weights.c_struct), B, _p(x_t), _p(frame_mask),
+                                      int(t), _p(self.film), _p(kv_t), _p(kv_p), _p(ws), ws.numel(), _p(logits),
+                                      _p(hidden), only_layers, flags, stream_ptr()), "d3pm_denoise_step")
+        return logits, hidden
+
+    def posterior_sample(self, logits, x_t, t, seed, utt0=0, flags=0, want_posterior=False):
+        cfg, B = self.cfg, x_t.shape[0]
+        logits = logits.contiguous()
+        x_next = torch.empty_like(x_t)
+        post = torch.empty((B, cfg.canvas, cfg.n_classes), dtype=torch.int16, device=self.device) if want_posterior else None
+        check(lib().d3pm_posterior_sample(C.byref(self.shape), B, _p(logits), dtype_code(logits.dtype), _p(x_t),
+                                          _p(x_next), int(t), C.byref(self.schedule.c_struct), seed, utt0, flags,
+                                          _p(post), stream_ptr()), "d3pm_posterior_sample")
+        return x_next, post
+
+    def sample_loop(self, x, frame_mask, t_start, t_stop, kv_t, kv_p, seed, utt0=0, flags=0, trace=False):
+        cfg, B = self.cfg, x.shape[0]
+        ws = self.workspace(B)
+        tr = torch.empty((t_start - t_stop, B, cfg.canvas), dtype=torch.int32, device=self.device) if trace else None
+        check(lib().d3pm_sample_loop(C.byref(self.shape), C.byref(self.weights.c_struct), B, _p(x), _p(frame_mask),
+                                     int(t_start), int(t_stop), _p(self.film), _p(kv_t), _p(kv_p),
+                                     C.byref(self.schedule.c_struct), seed, utt0, flags, _p(ws), ws.numel(), _p(tr),
+                                     stream_ptr()), "d3pm_sample_loop")
+        return tr
+
+    def q_sample(self, x0, frame_mask, t, seed, utt0=0):
+        out = torch.empty_like(x0)
+        check(lib().d3pm_q_sample(C.byref(self.shape), x0.shape[0], _p(x0), _p(out), _p(frame_mask), int(t),
+                                  C.byref(self.schedule.c_struct), seed, utt0, stream_ptr()), "d3pm_q_sample")
+        return out
+
+
+def uniform(seed: int, t: int, row0: int, rows: int, n_classes: int, stream_id: int, device) -> torch.Tensor:
+    out = torch.empty((rows, n_classes), dtype=torch.float32, device=device)
+    check(lib().d3pm_uniform(seed, t, row0, rows, n_classes, stream_id, _p(out), stream_ptr()), "d3pm_uniform")
+    return out
+
+
+def prof_enable(kclass: int, max_events: int):
+    check(lib().d3pm_prof_enable(kclass, max_events), "d3pm_prof_enable")
+
+
+def prof_read():
+    n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+    check(lib().d3pm_prof_read(C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "d3pm_prof_read")
+    return n.value, ms.value, fl.value, by.value
+
+
+def prof_disable():
+    lib().d3pm_prof_disable()

@@ -1,0 +1,244 @@
+"""Drop-in `AR` model of the discrete-diffusion (D3PM, absorbing state) codec-token sampler.
+
+Same public surface as the reference's /root/reference/vall_e/vall_e/ar_discrete.py `class AR`
+(ctor signature :205, `generate_audio` :696, `p_sample` :401, `q_sample` :467, `timesteps`,
+state-dict key layout :210-240) but the reverse process runs in hand-written HIP kernels for
+gfx950 behind the C ABI of include/d3pm_hip.h.  PyTorch only stores the weights, runs the two
+small once-per-utterance condition encoders (:216-230, 0.3 % of the reference's time) and provides
+the HIP stream.  There is no CPU or eager fallback for the diffusion loop.
+
+Differences from upstream, all opt-in or strictly more general:
+  * the ctor honours its arguments (upstream overrides them with d=32,H=16,L=8,steps=100, :207-238);
+    `AR.reference_native()` builds exactly the upstream shape;
+  * batches: upstream only works for one utterance (:699); here B utterances are B independent
+    runs (per-utterance Philox noise stream), returned as [B, canvas];
+  * noise comes from a counter-based Philox stream (`seed=`) instead of the CPU Mersenne generator;
+  * the 630 MB of dense transition tables are replaced by their 4 fp16 scalars per step.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import _hip
+from .synth import MASK_ID, N_CLASSES, D3PMConfig
+
+
+class _Mlp(nn.Module):
+    """timm-style Mlp (fc1 -> act -> fc2); state-dict keys fc1.*, fc2.* as upstream's timm import."""
+
+    def __init__(self, d_in, d_hidden, d_out, act):
+        super().__init__()
+        self.fc1 = nn.Linear(d_in, d_hidden)
+        self.act = act
+        self.fc2 = nn.Linear(d_hidden, d_out)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class _LevelSumEmbedding(nn.Module):
+    """Prompt embedding: sum over quantizer levels of per-level tables (base.py:244-274)."""
+
+    def __init__(self, n_levels, n_tokens, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(n_levels, n_tokens, d))
+
+    def forward(self, codes: Tensor) -> Tensor:
+        """codes int64 [..., S, l<=n_levels] -> [..., S, d]; fp32 sum, one rounding (the one-hot
+        contraction upstream accumulates the <= 8 non-zero terms in fp32)."""
+        w = self.weight
+        out = torch.zeros(codes.shape[:-1] + (w.shape[-1],), dtype=torch.float32, device=w.device)
+        for lvl in range(codes.shape[-1]):
+            out += F.embedding(codes[..., lvl], w[lvl]).float()
+        return out.to(w.dtype)
+
+
+class _DiTBlockParams(nn.Module):
+    """Parameter container with upstream's names (ar_discrete.py:103-124).  Never called: the
+    block forward is the HIP path.  cross_attn2 is kept so upstream state dicts load strictly."""
+
+    def __init__(self, d, heads):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(d, eps=1e-6)
+        self.attn = nn.MultiheadAttention(d, heads)
+        self.norm2 = nn.LayerNorm(d, eps=1e-6)
+        self.cross_attn = nn.MultiheadAttention(d, heads)
+        self.norm22 = nn.LayerNorm(d, eps=1e-6)
+        self.cross_attn2 = nn.MultiheadAttention(d, heads)
+        self.norm3 = nn.LayerNorm(d, eps=1e-6)
+        self.mlp = _Mlp(d, 4 * d, d, nn.GELU())
+        self.timestep_fc = nn.Linear(d, 2 * d)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("DiT blocks execute inside libd3pm_hip.so; call AR.generate_audio")
+
+
+def _sinusoid_table(n: int, d_model: int, dtype: torch.dtype) -> Tensor:
+    """[n, d] host table [sin | cos] as upstream's SinusodialEmbedding yields it (ar_discrete.py:41-72):
+    omega is *computed* in fp16, then follows the module dtype (`.half()` keeps it, `.float()` widens
+    the fp16 values) and the angles / sin / cos are evaluated in that dtype."""
+    half = d_model // 2
+    omega = torch.exp(-math.log(1e4) * (torch.arange(half, dtype=torch.float16) / half)).to(dtype)
+    ang = omega[None, :] * torch.arange(n)[:, None]
+    return torch.cat([ang.sin(), ang.cos()], dim=-1)
+
+
+class AR(nn.Module):
+    n_resp_levels = 1
+    num_classes = N_CLASSES
+
+    def __init__(self, d_model=512, n_steps=100, n_tokens=1024, max_n_levels=8, n_heads=8, num_layers=6, *,
+                 canvas: int = 448, n_frames: int = 350, s_text: int = 50, s_prompt: int = 398):
+        super().__init__()
+        if n_tokens + 1 != N_CLASSES:
+            raise ValueError("the absorbing-state tables assume 1024 codec ids + 1 mask id")
+        self.cfg = D3PMConfig(d_model=d_model, n_heads=n_heads, n_layers=num_layers, canvas=canvas, n_frames=n_frames,
+                              s_text=s_text, s_prompt=s_prompt, timesteps=n_steps, n_levels=max_n_levels)
+        cfg, d = self.cfg, d_model
+        self.timesteps = n_steps                       # read at call time, like upstream (:750)
+        self.text_emb = nn.Embedding(N_CLASSES, d, padding_idx=0)
+        self.proms_emb = _LevelSumEmbedding(max_n_levels, N_CLASSES, d)
+        self.resps_emb = nn.Embedding(N_CLASSES, d, padding_idx=0)
+        self.time_emb = nn.Embedding(n_steps + 1, d)
+        self.token_emb = nn.Embedding(N_CLASSES, d)    # unused upstream too; kept for state-dict parity
+
+        def encoder(mult):
+            layer = nn.TransformerEncoderLayer(d_model=d, nhead=cfg.cond_heads, dim_feedforward=cfg.cond_ff, dropout=0.0)
+            return nn.Sequential(nn.TransformerEncoder(layer, num_layers=cfg.cond_layers, enable_nested_tensor=False),
+                                 _Mlp(d, d * mult, d, nn.SiLU()))
+
+        self.encodertext = encoder(2)
+        self.encoder2 = encoder(3)
+        self.blocks = nn.ModuleList([_DiTBlockParams(d, n_heads) for _ in range(num_layers)])
+        self.final = nn.Linear(d, N_CLASSES)
+        self._pe_cache = {}
+        self.eps = 1.0e-6
+        self._sampler = None
+        self._sampler_key = None
+
+    # ------------------------------------------------------------------ construction helpers
+    @classmethod
+    def reference_native(cls) -> "AR":
+        """The only shape upstream's class can build: d=32, 16 heads, 8 blocks, 100 steps."""
+        return cls(d_model=32, n_steps=100, n_tokens=1024, max_n_levels=8, n_heads=16, num_layers=8)
+
+    @classmethod
+    def from_config(cls, cfg: D3PMConfig) -> "AR":
+        return cls(cfg.d_model, cfg.timesteps, cfg.n_classes - 1, cfg.n_levels, cfg.n_heads, cfg.n_layers,
+                   canvas=cfg.canvas, n_frames=cfg.n_frames, s_text=cfg.s_text, s_prompt=cfg.s_prompt)
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.final.weight.dtype
+
+    @property
+    def device(self) -> torch.device:
+        return self.final.weight.device
+
+    def _pe(self):
+        """(pe_text0 [1,d], pe_prompt [S_p,d]) in the model dtype on the model device, built on the host."""
+        key = (self.dtype, self.device)
+        if key not in self._pe_cache:
+            self._pe_cache[key] = (_sinusoid_table(1, self.cfg.d_model, self.dtype).to(self.device),
+                                   _sinusoid_table(self.cfg.s_prompt, self.cfg.d_model, self.dtype).to(self.device))
+        return self._pe_cache[key]
+
+    # ------------------------------------------------------------------ HIP sampler plumbing
+    def sampler(self) -> _hip.Sampler:
+        """(Re)binds the C-ABI pointer tables when weights moved or changed dtype."""
+        if self.device.type != "cuda":
+            raise RuntimeError("the D3PM sampler runs on MI355X only: move the model to a HIP device "
+                               "(model.to('cuda')); there is no CPU path")
+        sd = {k: v for k, v in self.named_parameters()}
+        key = (self.dtype, self.device, tuple((k, v.data_ptr(), v._version) for k, v in sd.items()
+                                              if k.startswith(("blocks.", "final.", "resps_emb", "time_emb"))))
+        if self._sampler is None or self._sampler_key != key:
+            with torch.cuda.device(self.device):
+                self._sampler = _hip.Sampler(self.cfg, {k: v.detach() for k, v in sd.items()}, self.dtype, self.device)
+            self._sampler_key = key
+        return self._sampler
+
+    # ------------------------------------------------------------------ conditioning (torch-ROCm)
+    @staticmethod
+    def _pad_rows(x: Tensor, n: int) -> Tensor:
+        if x.shape[0] >= n:
+            return x[:n]
+        return F.pad(x, [0, 0] * (x.dim() - 1) + [0, n - x.shape[0]])
+
+    def encode_conditions(self, text_list: Sequence[Tensor], proms_list: Sequence[Tensor]):
+        """-> (cond_text [B,S_t,d], cond_prompt [B,S_p,d]).  Same statements as upstream
+        (:711-746): zero pad / truncate, embed, text gets PE(position 0) on every phoneme (the
+        x.shape[0] quirk at :89), the prompt true positions; two post-norm encoder layers + Mlp."""
+        cfg, dev = self.cfg, self.device
+        text = torch.stack([self._pad_rows(t.to(dev).long(), cfg.s_text) for t in text_list])           # [B,S_t]
+        prom = torch.stack([self._pad_rows(p.to(dev).long(), cfg.s_prompt) for p in proms_list])        # [B,S_p,l]
+        pe_text0, pe_prompt = self._pe()
+        ct = self.text_emb(text) + pe_text0
+        cp = self.proms_emb(prom) + pe_prompt
+        # sequence-first batches: per-utterance arithmetic is what upstream's unbatched call does
+        ct = self.encodertext(ct.transpose(0, 1)).transpose(0, 1)
+        cp = self.encoder2(cp.transpose(0, 1)).transpose(0, 1)
+        return ct.contiguous(), cp.contiguous()
+
+    def canvas_init(self, batch: int, n_frames: Optional[int] = None):
+        """x_T: `n_frames` mask ids then zeros; the frame mask is fixed for the whole loop (:699-709)."""
+        cfg = self.cfg
+        n_frames = cfg.n_frames if n_frames is None else n_frames
+        if not 0 < n_frames <= cfg.canvas:
+            raise ValueError(f"n_frames must be in 1..{cfg.canvas}")
+        x = torch.zeros((batch, cfg.canvas), dtype=torch.int32, device=self.device)
+        x[:, :n_frames] = MASK_ID
+        frame_mask = (x[0] != 0).to(torch.uint8)
+        return x, frame_mask
+
+    # ------------------------------------------------------------------ the hot path
+    @torch.no_grad()
+    def generate_audio(self, text_list, proms_list, resps_list=None, *, steps: Optional[int] = None,
+                       n_frames: Optional[int] = None, seed: Optional[int] = None, greedy: bool = False,
+                       utt0: int = 0, return_trace: bool = False, flags: int = 0):
+        """Reverse diffusion for len(text_list) utterances.  Positional behaviour as upstream:
+        one utterance -> int64 [canvas] (squeezed, untrimmed; rows >= n_frames are sampled from
+        final.bias and meaningless).  `resps_list` is ignored, as upstream ignores it (:699)."""
+        if len(text_list) != len(proms_list) or len(text_list) == 0:
+            raise ValueError("text_list and proms_list must be non-empty and of equal length")
+        B = len(text_list)
+        smp = self.sampler()
+        t_start = (self.timesteps - 1) if steps is None else steps
+        if not 0 < t_start < smp.schedule.timesteps:
+            raise ValueError(f"steps must be in 1..{smp.schedule.timesteps - 1}")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # follows torch.manual_seed
+        with torch.cuda.device(self.device):
+            cond_text, cond_prompt = self.encode_conditions(text_list, proms_list)
+            kv_t, kv_p = smp.cond_kv(cond_text, cond_prompt)
+            x, frame_mask = self.canvas_init(B, n_frames)
+            fl = flags | (_hip.FLAG_GREEDY if greedy else 0)
+            trace = smp.sample_loop(x, frame_mask, t_start, 0, kv_t, kv_p, seed, utt0, fl, trace=return_trace)
+        out = x.long()
+        out = out[0] if B == 1 else out
+        return (out, trace) if return_trace else out
+
+    # ------------------------------------------------------------------ upstream method names
+    @torch.no_grad()
+    def p_sample(self, model_logits: Tensor, t: Tensor, x: Tensor, *, seed: int = 0, utt0: int = 0):
+        """One reverse transition from x0-logits [B,T,K] at step t[0] (ar_discrete.py:401-420).
+        Returns (sample int64 [B,T], softmax(logits)) like upstream."""
+        smp = self.sampler()
+        x_next, _ = smp.posterior_sample(model_logits, x.to(torch.int32).contiguous(), int(t.reshape(-1)[0]), seed, utt0)
+        return x_next.long(), F.softmax(model_logits, dim=-1)
+
+    @torch.no_grad()
+    def q_sample(self, x_start: Tensor, t: Tensor, mask: Tensor, *, seed: int = 0, utt0: int = 0):
+        """Forward noising q(x_t | x_0) (ar_discrete.py:467-487)."""
+        smp = self.sampler()
+        fm = mask.to(torch.uint8).contiguous()
+        return smp.q_sample(x_start.to(torch.int32).contiguous(), fm, int(t.reshape(-1)[0]), seed, utt0).long()
+
+    def forward(self, text_list, proms_list, resps_list=None, spkr_name=None):
+        raise NotImplementedError("training forward (ar_discrete.py:588-694) is outside the sampler's scope; "
+                                  "only generate_audio / p_sample / q_sample are implemented")
