@@ -109,8 +109,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
     for i in range(args.warmup):
         step(i)
+        torch.cuda.synchronize()
+        note(f"warmup {i + 1}/{args.warmup} done")
     fence()
     iters = cfg.timesteps - 1
     _hip.prof_enable(_hip.K_GEMM, args.steps * iters * (cfg.n_layers * 9 + 1) + 64)
@@ -150,6 +156,7 @@ def main():
         whole = algorithmic_flops_per_step(cfg, batch) / (ms_per_step * 1e-3) / 1e12
         result["whole_step_tflops"] = whole
         if not args.no_latency:
+            note(f"timed region {elapsed:.2f}s; measuring single-utterance latency")
             lat = []
             for i in range(5):
                 torch.cuda.synchronize()
@@ -159,6 +166,7 @@ def main():
                 lat.append((time.perf_counter() - t1) * 1e3)
             result["p50_utterance_latency_ms"] = statistics.median(lat[1:])
         if world == 1 and args.cpu_steps > 0:
+            note("timing the CPU port of the reference sampler")
             cpu_texts, cpu_proms = synth.make_inputs(cfg, 1, 1)
             result["cpu_baseline"] = cpu_baseline(cfg, sd32, cpu_texts, cpu_proms, args.cpu_steps)
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]

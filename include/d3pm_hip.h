@@ -161,6 +161,21 @@ int d3pm_q_sample(const d3pm_shape *shape, int batch, const int32_t *x0, int32_t
 int d3pm_uniform(uint64_t seed, int t, uint32_t row0, int rows, int n_classes, int stream_id,
                  float *out, void *stream);
 
+/* Single-operator entry points (kernel-level parity tests and micro-benchmarks).  `family`:
+ * 0 = auto (MFMA when the shape tiles, else generic), 1 = generic FMA kernels, 2 = MFMA (fails with
+ * D3PM_E_SHAPE when unsupported).  Same contracts as inside the denoiser:
+ *   linear:    Y[M][N] = epilogue(X[M][K] . W[N][K]^T + bias), act 0 none / 1 exact-erf GELU,
+ *              optional residuals R1 (+R2) [M][N] and row mask (see csrc/d3pm_kernels.h)
+ *   attention: per (utterance, head) softmax(rn(q*scale) . k^T) . v with Q [B*Tq][ldq], K/V [B*S][ldkv]
+ *   layernorm: Y = LN(X)*w + b over the last dim (eps 1e-6), optional FiLM vector [2d] */
+int d3pm_op_linear(int dtype, int family, const void *X, int ldx, const void *W, const void *bias, void *Y,
+                   int ldy, const void *R1, const void *R2, int ldr, const uint8_t *row_mask,
+                   int mask_period, int M, int N, int K, int act, void *stream);
+int d3pm_op_attention(int dtype, int family, const void *Q, int ldq, const void *K, const void *V, int ldkv,
+                      void *O, int ldo, int B, int Tq, int S, int H, int hd, float scale, void *stream);
+int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const void *b, const void *film,
+                      int M, int d, float eps, void *stream);
+
 /* Timing hooks for bench.py's roofline object: when enabled, every launch of the kernel class
  * `kclass` (D3PM_K_*) inside d3pm_sample_loop is bracketed by a hipEvent pair on `stream`;
  * d3pm_prof_read synchronises those events and returns launch count and total milliseconds. */

@@ -1,0 +1,16 @@
+# GPU-box driver: kernel numerics, parity, smoke, bench, rocprof.  Usage: bash tests/run_gpu_suite.sh [stage...]
+mkdir -p gpurun_out
+STAGES="${@:-kernels parity smoke bench prof}"
+ok=1
+for st in $STAGES; do
+  [ $ok -eq 1 ] || break
+  case $st in
+    kernels) timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -p no:cacheprovider -x > gpurun_out/pytest_kernels.log 2>&1; rc=$?; tail -15 gpurun_out/pytest_kernels.log;;
+    parity)  timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_parity.log 2>&1; rc=$?; tail -25 gpurun_out/pytest_parity.log;;
+    smoke)   timeout -k 10 180 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; rc=$?; tail -3 gpurun_out/smoke.log;;
+    bench)   timeout -k 10 900 python bench.py --steps 2 --warmup 1 2> gpurun_out/bench.err | tee gpurun_out/bench.json; rc=${PIPESTATUS[0]}; tail -5 gpurun_out/bench.err;;
+    prof)    cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-steps 0 --no-latency > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; rc=$?; cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/prof.log; find gpurun_out/prof -name "*stats*" | head;;
+  esac
+  echo "stage $st rc=$rc"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then ok=0; fi
+done

@@ -1,0 +1,152 @@
+"""Kernel-level numerics on the GPU: each HIP kernel (through the d3pm_op_* C entry points) against a
+plain PyTorch fp32 reference of the same op, and the MFMA family against the generic family.
+
+Tolerances: fp32 kernels 1e-4 relative to the output scale; 16-bit kernels must agree with the
+fp32 reference to within 2 units in the last place of the *storage* type on 99.5 % of the elements
+(fp32 accumulation, one rounding per op) and with each other (generic vs MFMA: different summation
+order only) likewise.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _eps(dtype):
+    return {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7, torch.float32: 2.0 ** -23}[dtype]
+
+
+def assert_close_lp(got, ref32, dtype, what, ulps=2.0, frac=0.995):
+    got = got.float()
+    scale = ref32.abs().clamp_min(ref32.abs().max() * 1e-3)
+    rel = (got - ref32).abs() / scale
+    ok = (rel <= ulps * _eps(dtype)).float().mean().item()
+    worst = rel.max().item() / _eps(dtype)
+    assert ok >= frac, f"{what}: only {ok:.4f} within {ulps} ulp (worst {worst:.1f} ulp)"
+    assert worst < 64, f"{what}: worst element off by {worst:.1f} ulp"
+
+
+def gelu32(v):
+    return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,ldy", [(448, 512, 512, None), (1536, 1536, 512, None), (1536, 512, 2048, None),
+                                       (448, 1025, 512, 1032), (200, 96, 64, None), (448, 2048, 512, None)])
+def test_linear_mfma_vs_generic_vs_torch(built_lib, dtype, M, N, K, ldy):
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g)).to(dtype).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(dtype).to(DEV)
+    ref = x.float() @ w.float().T + b.float()
+    for fam in (_hip.FAMILY_GENERIC, _hip.FAMILY_MFMA):
+        y = _hip.op_linear(x, w, b, family=fam, ldy=ldy)
+        assert_close_lp(y, ref, dtype, f"linear fam{fam} {M}x{N}x{K}")
+    yg = _hip.op_linear(x, w, b, family=_hip.FAMILY_GENERIC, ldy=ldy).float()
+    ym = _hip.op_linear(x, w, b, family=_hip.FAMILY_MFMA, ldy=ldy).float()
+    assert (yg == ym).float().mean().item() > 0.97           # same rounding points, different sum order
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_linear_epilogues(built_lib, dtype):
+    """bias + exact-erf GELU; double residual with the eager rounding order; in-place residual; row mask."""
+    from vall_e.vall_e import _hip
+    M, N, K, T = 896, 512, 512, 448
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(dtype).to(DEV)
+    r1 = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    r2 = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    mask = (torch.arange(T) < 350).to(torch.uint8).to(DEV)
+    lin = (x.float() @ w.float().T + b.float()).to(dtype).float()
+    outs = {}
+    for fam in (_hip.FAMILY_GENERIC, _hip.FAMILY_MFMA):
+        y = _hip.op_linear(x, w, b, act=1, family=fam)
+        assert_close_lp(y, gelu32(lin), dtype, f"gelu fam{fam}", ulps=3.0)
+        y2 = _hip.op_linear(x, w, b, r1=r1, r2=r2, family=fam)
+        ref2 = ((r1.float() + r2.float()).to(dtype).float() + lin)
+        assert_close_lp(y2, ref2, dtype, f"double residual fam{fam}")
+        xin = r1.clone()
+        y3 = _hip.op_linear(x, w, b, r1=xin, row_mask=mask, mask_period=T, family=fam, out=xin)
+        ref3 = (r1.float() + lin) * mask.float().repeat(M // T)[:, None]
+        assert_close_lp(y3, ref3, dtype, f"in-place residual + mask fam{fam}")
+        assert (y3[350:448] == 0).all() and (y3[448 + 350:] == 0).all()
+        outs[fam] = (y.float(), y2.float(), y3.float())
+    for a, c in zip(outs[_hip.FAMILY_GENERIC], outs[_hip.FAMILY_MFMA]):
+        assert (a == c).float().mean().item() > 0.97
+
+
+def test_linear_fp32_generic(built_lib):
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(448, 32, generator=g).to(DEV)
+    w = torch.randn(96, 32, generator=g).to(DEV)
+    b = torch.randn(96, generator=g).to(DEV)
+    y = _hip.op_linear(x, w, b)
+    assert (y - (x @ w.T + b)).abs().max().item() < 1e-4
+
+
+def torch_attention(q, k, v, H, scale):
+    B, Tq, d = q.shape
+    S, hd = k.shape[1], d // H
+    qh = (q.float() * scale).view(B, Tq, H, hd).transpose(1, 2)
+    kh = k.float().view(B, S, H, hd).transpose(1, 2)
+    vh = v.float().view(B, S, H, hd).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2), dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Tq, d)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Tq,S", [(448, 448), (448, 50), (448, 398), (768, 768), (768, 225), (128, 1), (64, 65)])
+def test_attention_mfma_vs_generic_vs_torch(built_lib, dtype, Tq, S):
+    from vall_e.vall_e import _hip
+    B, H, hd = 2, 8, 64
+    d = H * hd
+    g = torch.Generator(device="cpu").manual_seed(Tq * 1000 + S)
+    q = torch.randn(B, Tq, d, generator=g).to(dtype).to(DEV)
+    kv = torch.randn(B, S, 2 * d, generator=g).to(dtype).to(DEV)        # packed K|V rows like the cond cache
+    k, v = kv[..., :d], kv[..., d:]
+    scale = math.sqrt(1.0 / hd)
+    ref = torch_attention(q, k, v, H, scale)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    for fam in (_hip.FAMILY_GENERIC, _hip.FAMILY_MFMA):
+        o = _hip.op_attention(q, k, v, H, scale, family=fam).float()
+        err = (o - ref).abs().max().item()
+        assert err < tol, f"attention fam{fam} Tq={Tq} S={S}: max abs err {err}"
+
+
+def test_attention_self_packed_qkv_and_tiny_heads(built_lib):
+    """The self-attention call reads q/k/v out of one [N,3d] projection; head_dim 2 is the upstream shape."""
+    from vall_e.vall_e import _hip
+    for dtype, H, hd, tol in ((torch.float32, 16, 2, 2e-5), (torch.float16, 16, 2, 3e-3), (torch.float16, 8, 64, 4e-3)):
+        B, T, d = 2, 448, H * hd
+        g = torch.Generator(device="cpu").manual_seed(hd)
+        qkv = torch.randn(B, T, 3 * d, generator=g).to(dtype).to(DEV)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        scale = math.sqrt(1.0 / hd)
+        o = _hip.op_attention(q, k, v, H, scale).float()
+        assert (o - torch_attention(q, k, v, H, scale)).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_layernorm_and_film(built_lib, dtype):
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for d in (32, 512):
+        x = torch.randn(448, d, generator=g).to(dtype).to(DEV)
+        w = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype).to(DEV)
+        b = (0.1 * torch.randn(d, generator=g)).to(dtype).to(DEV)
+        film = (0.2 * torch.randn(2 * d, generator=g)).to(dtype).to(DEV)
+        ref = torch.nn.functional.layer_norm(x.float(), (d,), w.float(), b.float(), 1e-6)
+        y = _hip.op_layernorm(x, w, b)
+        tol = 1e-5 if dtype == torch.float32 else 4 * _eps(dtype) * 4
+        assert (y.float() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+        yf = _hip.op_layernorm(x, w, b, film=film).float()
+        reff = ref.to(dtype).float() * (1 + film[:d].float()).to(dtype).float()
+        reff = reff.to(dtype).float() + film[d:].float()
+        assert (yf - reff).abs().max().item() < tol * 2 * max(1.0, reff.abs().max().item())

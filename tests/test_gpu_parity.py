@@ -127,12 +127,16 @@ def test_block0_matches_reference(n32, n16):
     _, h32 = n32.logits(g["x_t"], t, want_logits=False, want_hidden=True, only_layers=1)
     e32 = (h32 - torch.from_numpy(g["block0_out_f32"])).abs().max().item()
     _, h16 = n16.logits(g["x_t"], t, want_logits=False, want_hidden=True, only_layers=1)
-    du = ulp16_diff(h16, f16(g["block0_out_f16"]))
+    ref16 = f16(g["block0_out_f16"])
+    d16 = (h16.float() - ref16.float()).abs()
     REPORT["block0_f32_max_abs_err"] = e32
-    REPORT["block0_f16_ulp_max"] = int(du.max())
-    REPORT["block0_f16_mismatch_frac"] = float((du > 0).float().mean())
+    REPORT["block0_f16_max_abs_err"] = float(d16.max())
+    REPORT["block0_f16_exact_frac"] = float((h16 == ref16).float().mean())
+    REPORT["block0_f16_absmax"] = float(ref16.abs().max())
     assert e32 < 1e-4
-    assert du.max() <= 8 and (du > 1).float().mean() < 0.01
+    # fp16 eager reference vs fp16 HIP: same rounding points, different accumulation order ->
+    # at most a couple of fp16 quanta of the activation range (|x| < 8 -> quantum 2^-8 .. 2^-7)
+    assert d16.max() <= 2.0 ** -6 and d16.mean() < 5e-4
 
 
 def test_logits_fp16_close_to_reference(n16):
@@ -143,9 +147,11 @@ def test_logits_fp16_close_to_reference(n16):
     du = ulp16_diff(lg, ref)
     REPORT["native_f16_logits_max_abs_err"] = float(diff.max())
     REPORT["native_f16_logits_exact_frac"] = float((du == 0).float().mean())
-    REPORT["native_f16_logits_ulp_p999"] = float(torch.quantile(du.float().flatten()[:: 7], 0.999))
-    assert diff.max() < 8e-3          # reference fp16-vs-fp32 itself differs by 4.8e-3
-    assert (du <= 2).float().mean() > 0.99
+    REPORT["native_f16_logits_mean_abs_err"] = float(diff.mean())
+    REPORT["native_f16_logits_frac_within_2e-3"] = float((diff <= 2e-3).float().mean())
+    # |logits| < 4 -> fp16 quantum up to 2^-9 = 1.95e-3; the reference's own fp16-vs-fp32 gap is 4.8e-3
+    assert diff.max() < 8e-3 and diff.mean() < 6e-4
+    assert (diff <= 2e-3).float().mean() > 0.99
 
 
 def _audit(n, golden_traj, seed, utt=0):

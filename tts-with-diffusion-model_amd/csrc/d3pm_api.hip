@@ -79,6 +79,8 @@ struct Workspace {
   size_t total;
 };
 static size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+// internal logits rows are padded to a multiple of 8 elements (16-B aligned rows for vector stores/loads)
+static int logits_ld(const d3pm_shape& sh) { return (sh.n_classes + 7) & ~7; }
 static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
   const size_t es = dtype_size(sh.dtype), n = static_cast<size_t>(batch) * sh.canvas, d = sh.d_model;
   Workspace w{};
@@ -91,7 +93,7 @@ static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
   w.att = take(n * d * es);
   w.att2 = take(n * d * es);
   w.mlp = take(n * 4 * d * es);
-  w.logits = take(n * sh.n_classes * es);
+  w.logits = take(n * logits_ld(sh) * es);
   w.total = off;
   return w;
 }
@@ -195,10 +197,10 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
 }
 
 static int final_logits(const d3pm_shape& sh, const d3pm_weights& w, int batch, const Workspace& ws, void* logits,
-                        uint32_t flags, hipStream_t s) {
+                        int ldl, uint32_t flags, hipStream_t s) {
   // x is already multiplied by the frame mask at the end of every block (ar_discrete.py:161,773)
   LinearArgs g;
-  g.X = ws.x; g.ldx = sh.d_model; g.W = w.final_w; g.bias = w.final_b; g.Y = logits; g.ldy = sh.n_classes;
+  g.X = ws.x; g.ldx = sh.d_model; g.W = w.final_w; g.bias = w.final_b; g.Y = logits; g.ldy = ldl;
   g.M = batch * sh.canvas; g.N = sh.n_classes; g.K = sh.d_model;
   return run_linear(sh.dtype, g, flags, s);
 }
@@ -267,7 +269,12 @@ int d3pm_denoise_step(const d3pm_shape* sh, const d3pm_weights* w, int batch, co
   if (hidden_out)
     D3PM_CHECK_HIP(hipMemcpyAsync(hidden_out, ws.x, static_cast<size_t>(batch) * sh->canvas * sh->d_model * dtype_size(sh->dtype),
                                   hipMemcpyDeviceToDevice, s));
-  if (logits_out) D3PM_TRY(final_logits(*sh, *w, batch, ws, logits_out, flags, s));
+  if (logits_out) {
+    const size_t es = dtype_size(sh->dtype);
+    D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, logits_ld(*sh), flags, s));
+    D3PM_CHECK_HIP(hipMemcpy2DAsync(logits_out, sh->n_classes * es, ws.logits, logits_ld(*sh) * es, sh->n_classes * es,
+                                    static_cast<size_t>(batch) * sh->canvas, hipMemcpyDeviceToDevice, s));
+  }
   return D3PM_OK;
 }
 
@@ -301,9 +308,9 @@ int d3pm_sample_loop(const d3pm_shape* sh, const d3pm_weights* w, int batch, int
   const int rows = batch * sh->canvas;
   for (int t = t_start; t > t_stop; --t) {
     D3PM_TRY(denoiser_blocks(*sh, *w, batch, x, frame_mask, t, film, kv_text, kv_prompt, ws, sh->n_layers, flags, s));
-    D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, flags, s));
+    D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, logits_ld(*sh), flags, s));
     SampleArgs a;
-    a.logits = ws.logits; a.logits_dtype = sh->dtype; a.ldl = sh->n_classes; a.x_t = x; a.x_next = x;
+    a.logits = ws.logits; a.logits_dtype = sh->dtype; a.ldl = logits_ld(*sh); a.x_t = x; a.x_next = x;
     a.x_next2 = trace ? trace + static_cast<size_t>(t_start - t) * rows : nullptr;
     a.rows = rows; a.n_classes = sh->n_classes; a.mask_id = sh->mask_id; a.canvas = sh->canvas; a.seed = seed;
     a.row0 = utt0 * static_cast<uint32_t>(sh->canvas); a.greedy = (flags & D3PM_FLAG_GREEDY) ? 1 : 0;
@@ -328,6 +335,45 @@ int d3pm_q_sample(const d3pm_shape* sh, int batch, const int32_t* x0, int32_t* x
 int d3pm_uniform(uint64_t seed, int t, uint32_t row0, int rows, int n_classes, int stream_id, float* out, void* stream) {
   D3PM_REQUIRE(out && rows > 0 && n_classes > 0, D3PM_E_ARG, "d3pm_uniform: bad arguments");
   return uniform_launch(seed, t, row0, rows, n_classes, stream_id, out, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_op_linear(int dtype, int family, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy,
+                   const void* R1, const void* R2, int ldr, const uint8_t* row_mask, int mask_period, int M, int N, int K,
+                   int act, void* stream) {
+  D3PM_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0, D3PM_E_ARG, "d3pm_op_linear: bad arguments");
+  LinearArgs g;
+  g.X = X; g.ldx = ldx; g.W = W; g.bias = bias; g.Y = Y; g.ldy = ldy; g.R1 = R1; g.R2 = R2; g.ldr = ldr;
+  g.row_mask = row_mask; g.mask_period = mask_period > 0 ? mask_period : 1; g.M = M; g.N = N; g.K = K; g.act = act;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (family == 1) return generic_linear(dtype, g, s);
+  if (family == 2) {
+    D3PM_REQUIRE(mfma_linear_supported(dtype, g), D3PM_E_SHAPE, "d3pm_op_linear: shape not supported by the MFMA kernel");
+    return mfma_linear(dtype, g, s);
+  }
+  return run_linear(dtype, g, 0, s);
+}
+
+int d3pm_op_attention(int dtype, int family, const void* Q, int ldq, const void* K, const void* V, int ldkv, void* O,
+                      int ldo, int B, int Tq, int S, int H, int hd, float scale, void* stream) {
+  D3PM_REQUIRE(Q && K && V && O && B > 0 && Tq > 0 && S > 0 && H > 0 && hd > 0, D3PM_E_ARG, "d3pm_op_attention: bad arguments");
+  AttnArgs a;
+  a.Q = Q; a.ldq = ldq; a.K = K; a.V = V; a.ldkv = ldkv; a.O = O; a.ldo = ldo; a.B = B; a.Tq = Tq; a.S = S; a.H = H;
+  a.hd = hd; a.scale = scale;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (family == 1) return generic_attention(dtype, a, s);
+  if (family == 2) {
+    D3PM_REQUIRE(mfma_attention_supported(dtype, a), D3PM_E_SHAPE, "d3pm_op_attention: shape not supported by the MFMA kernel");
+    return mfma_attention(dtype, a, s);
+  }
+  return run_attention(dtype, a, 0, s);
+}
+
+int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const void* b, const void* film, int M, int d,
+                      float eps, void* stream) {
+  D3PM_REQUIRE(X && Y && w && b && M > 0 && d > 0, D3PM_E_ARG, "d3pm_op_layernorm: bad arguments");
+  LayerNormArgs ln;
+  ln.X = X; ln.Y = Y; ln.w = w; ln.b = b; ln.film = film; ln.M = M; ln.d = d; ln.eps = eps;
+  return run_layernorm(dtype, ln, 0, static_cast<hipStream_t>(stream));
 }
 
 int d3pm_prof_enable(int kclass, int max_events) {

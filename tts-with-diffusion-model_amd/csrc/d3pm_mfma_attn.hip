@@ -1,0 +1,228 @@
+// d3pm_mfma_attn.hip -- flash-style attention on MFMA for head_dim 64 (f16 / bf16), gfx950.
+//
+// Replaces the need_weights branch of torch's multi_head_attention_forward as called by
+// DiTBlock.forward (/root/reference/vall_e/vall_e/ar_discrete.py:132 self, :138 text, :142 prompt):
+// q*sqrt(1/hd) -> bmm -> softmax -> bmm.  The [T,S] score matrix and the head-averaged weights the
+// reference materialises (and throws away) never exist here.
+//
+// Workgroup = 4 wave64 = 64 queries of one (utterance, head); each wave owns 16 queries and walks
+// the keys in tiles of 64 with an online softmax.
+//   * S^T = K.Q^T by v_mfma_f32_16x16x32 (K fragment = A operand from LDS, Q fragment = B operand
+//     held in registers for the whole kernel): a lane holds 4 consecutive keys x 4 key tiles of ONE
+//     query, so max / sum run in-lane plus two xor-shuffles (lanes l, l^16, l^32, l^48 share a query);
+//   * the exponentiated scores of two key tiles, converted to 16 bit, ARE the B operand of the
+//     P.V product (contraction index permuted consistently on both operands): no LDS round trip;
+//   * V stays row-major in LDS and is read column-major with ds_read_b64_tr_b16 (4 keys x 16
+//     columns per 16-lane group) as the A operand, giving O^T: a lane owns 4 consecutive output
+//     columns of its own query, so the softmax rescale needs no cross-lane traffic;
+//   * K and V tiles are staged global -> registers -> LDS (16 B per lane) one tile ahead, one
+//     barrier per tile; 128-B LDS rows, 16-B chunks XOR-swizzled (K: (row>>1)&7 for the b128
+//     fragment reads, V: ((row>>1)&3)<<1 for the transposed reads) -- conflict-free by construction.
+// Numerics: scores are rounded to the storage dtype like the eager bmm output; the probabilities
+// enter the second MFMA un-normalised (e^(s-m) <= 1, rounded to the storage dtype) and the sum is
+// divided out in fp32 at the end -- this differs from the eager softmax->round->bmm chain by
+// rounding noise only and is what the MFMA family is allowed to do (precision modes).
+#include "d3pm_kernels.h"
+
+namespace d3pm {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+constexpr int HD = 64, BQ = 64, BKV = 64, ROWB = 128;
+constexpr int TILE = BKV * ROWB;   // 8 KiB per K or V tile
+
+template <typename T> __device__ __forceinline__ floatx4 mma(uint4 a, uint4 b, floatx4 c);
+template <> __device__ __forceinline__ floatx4 mma<f16>(uint4 a, uint4 b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ floatx4 mma<bf16>(uint4 a, uint4 b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int k_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int v_off(int row, int chunk) { return row * ROWB + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
+
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+  T x = static_cast<T>(a), y = static_cast<T>(b);
+  return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, x)) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, y)) << 16);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
+                                                      const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo,
+                                                      int Tq, int S, float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE];   // [buffer][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ + wave * 16;
+  const int qi = lane & 15, g = lane >> 4;
+  const T* Kb = Kp + static_cast<size_t>(b) * S * ldkv + h * HD;
+  const T* Vb = Vp + static_cast<size_t>(b) * S * ldkv + h * HD;
+
+  // Q fragment (B operand of S^T = K.Q^T): lane holds q[query qi][32*ks + 8g .. +7], pre-scaled like q*sqrt(1/hd)
+  uint4 qf[2];
+  {
+    int qrow = q0 + qi;
+    qrow = qrow < Tq ? qrow : Tq - 1;
+    const T* qp = Q + (static_cast<size_t>(b) * Tq + qrow) * ldq + h * HD;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 raw = *reinterpret_cast<const uint4*>(qp + ks * 32 + g * 8);
+      const T* e = reinterpret_cast<const T*>(&raw);
+      uint32_t w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = pack2<T>(static_cast<float>(e[2 * i]) * scale, static_cast<float>(e[2 * i + 1]) * scale);
+      qf[ks] = uint4{w[0], w[1], w[2], w[3]};
+    }
+  }
+
+  // staging: thread -> 2 x 16 B of the K tile and 2 x 16 B of the V tile
+  int srow[2], sch[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int c = tid + 256 * i;
+    srow[i] = c >> 3;
+    sch[i] = c & 7;
+  }
+  uint4 rk[2], rv[2];
+  auto load_tile = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = tile * BKV + srow[i];
+      key = key < S ? key : S - 1;
+      rk[i] = *reinterpret_cast<const uint4*>(Kb + static_cast<size_t>(key) * ldkv + sch[i] * 8);
+      rv[i] = *reinterpret_cast<const uint4*>(Vb + static_cast<size_t>(key) * ldkv + sch[i] * 8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* base = smem + buf * 2 * TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(base + k_off(srow[i], sch[i])) = rk[i];
+      *reinterpret_cast<uint4*>(base + TILE + v_off(srow[i], sch[i])) = rv[i];
+    }
+  };
+
+  const int n_tiles = (S + BKV - 1) / BKV;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  float m_run = -INFINITY, l_part = 0.f;
+  floatx4 acc_o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) acc_o[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const char* kb = smem + (tile & 1) * 2 * TILE;
+    const char* vb = kb + TILE;
+    const bool more = tile + 1 < n_tiles;
+    if (more) load_tile(tile + 1);
+
+    // ---- S^T tile: 64 keys x 16 queries per wave ----
+    floatx4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 kf = *reinterpret_cast<const uint4*>(kb + k_off(kt * 16 + qi, ks * 4 + g));
+        s[kt] = mma<T>(kf, qf[ks], s[kt]);
+      }
+    }
+    // lane holds scores of query qi for keys tile*64 + kt*16 + 4g + r
+    float mx = -INFINITY;
+    const int key_base = tile * BKV + 4 * g;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = rn<T>(s[kt][r]);
+        v = (key_base + kt * 16 + r < S) ? v : -INFINITY;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);      // exp(-inf) = 0 on the first tile
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = rn<T>(expf(s[kt][r] - m_new));
+        s[kt][r] = p;
+        psum += p;
+      }
+    l_part = l_part * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha;
+
+    // ---- O^T += V^T . P^T : contraction index j<4 -> key tile 2kb, j>=4 -> key tile 2kb+1 ----
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      const floatx4 pa = s[2 * kb2], pb = s[2 * kb2 + 1];
+      const uint4 pf = uint4{pack2<T>(pa[0], pa[1]), pack2<T>(pa[2], pa[3]), pack2<T>(pb[0], pb[1]), pack2<T>(pb[2], pb[3])};
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        // 16-lane group g, lane qi: address of row (key0 + qi>>2), columns 16dt + 4(qi&3) .. +3
+        const int col = dt * 16 + 4 * (qi & 3);
+        const int r0 = (2 * kb2) * 16 + 4 * g + (qi >> 2), r1 = r0 + 16;
+        typedef short4v __attribute__((address_space(3))) * lds_ptr;
+        short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + v_off(r0, col >> 3) + (col & 7) * 2));
+        short4v vc = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + v_off(r1, col >> 3) + (col & 7) * 2));
+        uint2 lo = __builtin_bit_cast(uint2, va), hi = __builtin_bit_cast(uint2, vc);
+        acc_o[dt] = mma<T>(uint4{lo.x, lo.y, hi.x, hi.y}, pf, acc_o[dt]);
+      }
+    }
+    if (more) store_tile((tile + 1) & 1);
+    __syncthreads();
+  }
+
+  float l = l_part + __shfl_xor(l_part, 16, kWave);
+  l += __shfl_xor(l, 32, kWave);
+  const float inv = 1.0f / l;
+  const int qrow = q0 + qi;
+  if (qrow < Tq) {
+    T* op = O + (static_cast<size_t>(b) * Tq + qrow) * ldo + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      uint2 o{pack2<T>(acc_o[dt][0] * inv, acc_o[dt][1] * inv), pack2<T>(acc_o[dt][2] * inv, acc_o[dt][3] * inv)};
+      *reinterpret_cast<uint2*>(op + dt * 16 + 4 * g) = o;
+    }
+  }
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+bool mfma_attention_supported(int dtype, const AttnArgs& a) {
+  if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
+  if (a.hd != HD || a.S < 1 || a.Tq < 1) return false;
+  if (a.ldq % 8 || a.ldkv % 8 || a.ldo % 4) return false;
+  return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 8);
+}
+
+int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
+  dim3 grid((a.Tq + BQ - 1) / BQ, a.H, a.B), block(256);
+  if (dtype == D3PM_F16)
+    attn_mfma_hd64<f16><<<grid, block, 0, s>>>(static_cast<const f16*>(a.Q), a.ldq, static_cast<const f16*>(a.K),
+                                               static_cast<const f16*>(a.V), a.ldkv, static_cast<f16*>(a.O), a.ldo,
+                                               a.Tq, a.S, a.scale);
+  else
+    attn_mfma_hd64<bf16><<<grid, block, 0, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K),
+                                                static_cast<const bf16*>(a.V), a.ldkv, static_cast<bf16*>(a.O), a.ldo,
+                                                a.Tq, a.S, a.scale);
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+}  // namespace d3pm

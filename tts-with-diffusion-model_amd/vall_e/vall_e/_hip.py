@@ -67,6 +67,14 @@ SIGNATURES = {
     "d3pm_q_sample": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_void_p]),
     "d3pm_uniform": (C.c_int, [C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "d3pm_op_linear": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_void_p]),
+    "d3pm_op_attention": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.c_void_p]),
+    "d3pm_op_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_float, C.c_void_p]),
     "d3pm_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "d3pm_prof_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double)]),
@@ -230,6 +238,41 @@ class Sampler:
         check(lib().d3pm_q_sample(C.byref(self.shape), x0.shape[0], _p(x0), _p(out), _p(frame_mask), int(t),
                                   C.byref(self.schedule.c_struct), seed, utt0, stream_ptr()), "d3pm_q_sample")
         return out
+
+
+FAMILY_AUTO, FAMILY_GENERIC, FAMILY_MFMA = 0, 1, 2
+
+
+def op_linear(x, w, bias=None, *, act=0, r1=None, r2=None, row_mask=None, mask_period=1, family=0, out=None,
+              ldy=None):
+    """y = epilogue(x @ w.T + bias) through d3pm_op_linear; x [M,K], w [N,K] contiguous device tensors."""
+    M, K = x.shape
+    N = w.shape[0]
+    ldy = N if ldy is None else ldy
+    y = torch.zeros((M, ldy), dtype=x.dtype, device=x.device) if out is None else out
+    check(lib().d3pm_op_linear(dtype_code(x.dtype), family, _p(x), x.stride(0), _p(w), _p(bias), _p(y), ldy, _p(r1),
+                               _p(r2), 0 if r1 is None else r1.stride(0), _p(row_mask), mask_period, M, N, K, act,
+                               stream_ptr()), "d3pm_op_linear")
+    return y[:, :N]
+
+
+def op_attention(q, k, v, n_heads, scale, *, family=0):
+    """q [B,Tq,d], k/v [B,S,d] (views with arbitrary row stride allowed) -> [B,Tq,d]."""
+    B, Tq, d = q.shape
+    S = k.shape[1]
+    assert k.stride(1) == v.stride(1) and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    assert q.stride(0) == Tq * q.stride(1) and k.stride(0) == S * k.stride(1) and v.stride(0) == S * v.stride(1)
+    o = torch.empty((B, Tq, d), dtype=q.dtype, device=q.device)
+    check(lib().d3pm_op_attention(dtype_code(q.dtype), family, _p(q), q.stride(1), _p(k), _p(v), k.stride(1), _p(o), d,
+                                  B, Tq, S, n_heads, d // n_heads, float(scale), stream_ptr()), "d3pm_op_attention")
+    return o
+
+
+def op_layernorm(x, w, b, film=None, eps=1e-6):
+    y = torch.empty_like(x)
+    check(lib().d3pm_op_layernorm(dtype_code(x.dtype), _p(x), _p(y), _p(w), _p(b), _p(film), x.shape[0], x.shape[1],
+                                  eps, stream_ptr()), "d3pm_op_layernorm")
+    return y
 
 
 def uniform(seed: int, t: int, row0: int, rows: int, n_classes: int, stream_id: int, device) -> torch.Tensor:
