@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--config", default="libritts", choices=["libritts", "native", "vctk"])
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--cpu-steps", type=int, default=8, help="diffusion iterations timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=4, help="diffusion iterations timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-latency", action="store_true")
     return ap.parse_args()
 
@@ -48,13 +48,31 @@ def algorithmic_flops_per_step(cfg, batch):
     return float(f_tok) * batch * T * (cfg.timesteps - 1)
 
 
+def note(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """Threads this process may really use: scheduler affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(cfg, sd32, texts, proms, n_iters):
     """The oracle (op-for-op port of the reference sampler incl. its dense 1025x1025 table matmuls
     and need_weights=True attention), fp16 like the reference, on all host cores, for `n_iters`
     diffusion iterations of ONE utterance; extrapolated to the full 99-iteration utterance."""
     from oracle import d3pm_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    note(f"cpu_baseline: {cores} threads; building the reference-style dense tables")
     orc = O.Oracle({k: v.half() for k, v in sd32.items()}, O.Shape.of(cfg), dense=True)
     noise = O.philox_noise(123, cfg.canvas)
     with torch.no_grad():
@@ -62,9 +80,11 @@ def cpu_baseline(cfg, sd32, texts, proms, n_iters):
         x, mask = orc.canvas_init()
         cp, ct = orc.conditions(texts[0], proms[0])
         t_cond = time.perf_counter() - t0
+        note(f"cpu_baseline: condition encoders {t_cond:.2f}s")
         t0 = time.perf_counter()
         for t in range(cfg.timesteps - 1, cfg.timesteps - 1 - n_iters, -1):
             x = orc.step(x, t, cp, ct, mask, noise(t, 0))
+            note(f"cpu_baseline: iteration t={t} done at {time.perf_counter() - t0:.2f}s")
         t_iter = (time.perf_counter() - t0) / n_iters
     per_utt = t_cond + t_iter * (cfg.timesteps - 1)
     return {"value": cfg.n_frames / per_utt, "unit": "codec_tokens/s", "cores": cores, "kind": "port",
@@ -108,10 +128,6 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
-
-    def note(msg):
-        if rank == 0:
-            print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     for i in range(args.warmup):
         step(i)

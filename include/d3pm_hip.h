@@ -176,6 +176,12 @@ int d3pm_op_attention(int dtype, int family, const void *Q, int ldq, const void 
 int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const void *b, const void *film,
                       int M, int d, float eps, void *stream);
 
+/* Tuning knobs (process-wide; defaults are what bench.py measures).
+ * D3PM_TUNE_GEMM_VARIANT: 0 register-staged double buffer, 1 direct-to-LDS double buffer,
+ *                         2 direct-to-LDS single buffer (4 workgroups per CU). */
+enum { D3PM_TUNE_GEMM_VARIANT = 0 };
+int d3pm_set_tuning(int knob, int value);
+
 /* Timing hooks for bench.py's roofline object: when enabled, every launch of the kernel class
  * `kclass` (D3PM_K_*) inside d3pm_sample_loop is bracketed by a hipEvent pair on `stream`;
  * d3pm_prof_read synchronises those events and returns launch count and total milliseconds. */

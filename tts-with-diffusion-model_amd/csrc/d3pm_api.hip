@@ -24,6 +24,7 @@ void set_error(const char* fmt, ...) {
 int q_sample_launch(const d3pm_shape*, int, const int32_t*, int32_t*, const uint8_t*, int, const d3pm_schedule*,
                     uint64_t, uint32_t, hipStream_t);
 int uniform_launch(uint64_t, int, uint32_t, int, int, int, float*, hipStream_t);
+void set_gemm_variant(int v);
 
 // ---- profiling hooks (bench.py roofline object) ----------------------------------------------
 struct Prof {
@@ -69,7 +70,7 @@ static int run_attention(int dtype, const AttnArgs& a, uint32_t flags, hipStream
 }
 static int run_layernorm(int dtype, const LayerNormArgs& a, uint32_t flags, hipStream_t s) {
   ProfScope p(D3PM_K_LN, s, 0.0, dtype_size(dtype) * static_cast<double>(a.M) * a.d * (a.Y2 ? 3.0 : 2.0));
-  (void)flags;
+  if (!(flags & D3PM_FLAG_FORCE_GENERIC) && fast_layernorm_supported(dtype, a)) return fast_layernorm(dtype, a, s);
   return generic_layernorm(dtype, a, s);
 }
 
@@ -374,6 +375,12 @@ int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const vo
   LayerNormArgs ln;
   ln.X = X; ln.Y = Y; ln.w = w; ln.b = b; ln.film = film; ln.M = M; ln.d = d; ln.eps = eps;
   return run_layernorm(dtype, ln, 0, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_set_tuning(int knob, int value) {
+  D3PM_REQUIRE(knob == D3PM_TUNE_GEMM_VARIANT && value >= 0 && value <= 2, D3PM_E_ARG, "d3pm_set_tuning: unknown knob/value");
+  set_gemm_variant(value);
+  return D3PM_OK;
 }
 
 int d3pm_prof_enable(int kclass, int max_events) {

@@ -82,6 +82,7 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a);
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s);
 bool mfma_attention_supported(int dtype, const AttnArgs& a);
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s);
+bool fast_layernorm_supported(int dtype, const LayerNormArgs& a);
 int fast_layernorm(int dtype, const LayerNormArgs& a, hipStream_t s);
 
 PosteriorConsts make_posterior_consts(const d3pm_schedule* sched, int t);

@@ -46,6 +46,69 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 template <typename T> struct Pack4 { T v[4]; };
 
 template <typename T>
+__device__ __forceinline__ void epilogue_store(floatx4 (&acc)[4][4], const T* __restrict__ bias, T* Y, int ldy,
+                                               const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
+                                               int mask_period, int M, int N, int act, int mw0, int nw0, int lane) {
+  // epilogue: lane holds D[n = nt*16 + (lane>>4)*4 + r][m = mt*16 + (lane&15)], r = 0..3
+  const int nq = (lane >> 4) * 4;
+  float bv[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nw0 + nt * 16 + nq + r;
+      bv[nt][r] = (bias && n < N) ? static_cast<float>(bias[n]) : 0.f;
+    }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = mw0 + mt * 16 + (lane & 15);
+    if (m >= M) continue;
+    const float mk = row_mask ? (row_mask[m % mask_period] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = nw0 + nt * 16 + nq;
+      if (n >= N) continue;
+      const bool full = n + 3 < N;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = rn<T>(acc[nt][mt][r] + bv[nt][r]);
+        if (act == ACT_GELU) v[r] = rn<T>(gelu_erf(v[r]));
+      }
+      if (R1) {
+        const T* r1 = R1 + static_cast<size_t>(m) * ldr + n;
+        const T* r2 = R2 ? R2 + static_cast<size_t>(m) * ldr + n : nullptr;
+        if (full) {
+          Pack4<T> p1 = *reinterpret_cast<const Pack4<T>*>(r1), p2{};
+          if (r2) p2 = *reinterpret_cast<const Pack4<T>*>(r2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float res = static_cast<float>(p1.v[r]);
+            if (r2) res = rn<T>(res + static_cast<float>(p2.v[r]));
+            v[r] = rn<T>(res + v[r]);
+          }
+        } else {
+          for (int r = 0; r < 4 && n + r < N; ++r) {
+            float res = static_cast<float>(r1[r]);
+            if (r2) res = rn<T>(res + static_cast<float>(r2[r]));
+            v[r] = rn<T>(res + v[r]);
+          }
+        }
+      }
+      T* y = Y + static_cast<size_t>(m) * ldy + n;
+      if (full) {
+        Pack4<T> o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.v[r] = static_cast<T>(v[r] * mk);
+        *reinterpret_cast<Pack4<T>*>(y) = o;
+      } else {
+        for (int r = 0; r < 4 && n + r < N; ++r) y[r] = static_cast<T>(v[r] * mk);
+      }
+    }
+  }
+}
+
+template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_128(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                         const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                         const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
@@ -126,63 +189,86 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128(const T* __restrict__ X,
     __syncthreads();
   }
 
-  // epilogue: lane holds D[n = nt*16 + (lane>>4)*4 + r][m = mt*16 + (lane&15)], r = 0..3
-  const int nq = (lane >> 4) * 4;
-  float bv[4][4];
+  epilogue_store<T>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, act, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+
+// ---- variant 2: direct-to-LDS staging (global_load_lds_dwordx4) -------------------------------------
+// Each wave-instruction lands 1 KiB = 8 rows x 128 B linearly in LDS (wave-uniform base + lane*16), so the
+// XOR swizzle is applied to the per-lane SOURCE address (logical chunk = lane&7 ^ f(row)) and undone by the
+// same lds_off() on the fragment reads.  No staging VGPRs, no ds_write pass.
+typedef __attribute__((address_space(3))) void* lds_void;
+typedef const __attribute__((address_space(1))) void* glb_void;
+
+template <typename T, int NBUF>   // NBUF 2: next tile's DMA issued before the MFMAs; NBUF 1: 32 KiB LDS, 4 workgroups per CU
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_mfma_128_glds(const T* __restrict__ X, int ldx, const T* __restrict__ W,
+                                                             const T* __restrict__ bias, T* Y, int ldy, const T* R1,
+                                                             const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
+                                                             int mask_period, int M, int N, int K, int act, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const T* gx[4];
+  const T* gw[4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 64 + nt * 16 + nq + r;
-      bv[nt][r] = (bias && n < N) ? static_cast<float>(bias[n]) : 0.f;
-    }
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + (lane & 15);
-    if (m >= M) continue;
-    const float mk = row_mask ? (row_mask[m % mask_period] ? 1.f : 0.f) : 1.f;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + wn * 64 + nt * 16 + nq;
-      if (n >= N) continue;
-      const bool full = n + 3 < N;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = rn<T>(acc[nt][mt][r] + bv[nt][r]);
-        if (act == ACT_GELU) v[r] = rn<T>(gelu_erf(v[r]));
-      }
-      if (R1) {
-        const T* r1 = R1 + static_cast<size_t>(m) * ldr + n;
-        const T* r2 = R2 ? R2 + static_cast<size_t>(m) * ldr + n : nullptr;
-        if (full) {
-          Pack4<T> p1 = *reinterpret_cast<const Pack4<T>*>(r1), p2{};
-          if (r2) p2 = *reinterpret_cast<const Pack4<T>*>(r2);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float res = static_cast<float>(p1.v[r]);
-            if (r2) res = rn<T>(res + static_cast<float>(p2.v[r]));
-            v[r] = rn<T>(res + v[r]);
-          }
-        } else {
-          for (int r = 0; r < 4 && n + r < N; ++r) {
-            float res = static_cast<float>(r1[r]);
-            if (r2) res = rn<T>(res + static_cast<float>(r2[r]));
-            v[r] = rn<T>(res + v[r]);
-          }
-        }
-      }
-      T* y = Y + static_cast<size_t>(m) * ldy + n;
-      if (full) {
-        Pack4<T> o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o.v[r] = static_cast<T>(v[r] * mk);
-        *reinterpret_cast<Pack4<T>*>(y) = o;
-      } else {
-        for (int r = 0; r < 4 && n + r < N; ++r) y[r] = static_cast<T>(v[r] * mk);
-      }
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    int mr = m0 + row, nr = n0 + row;
+    mr = mr < M ? mr : M - 1;
+    nr = nr < N ? nr : N - 1;
+    gx[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
+    gw[i] = W + static_cast<size_t>(nr) * K + logical * 8;
   }
+  auto issue = [&](int kt, int buf) {
+    char* base = smem + buf * 2 * TILE_BYTES + (wave * 4) * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void)(gx[i] + kt * BK), (lds_void)(base + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void)(gw[i] + kt * BK), (lds_void)(base + TILE_BYTES + i * 1024), 16, 0, 0);
+    }
+  };
+  if (NBUF == 2) {
+    issue(0, 0);
+    __syncthreads();
+  }
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  const int nk = K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* bufA = smem + (NBUF == 2 ? (kt & 1) : 0) * 2 * TILE_BYTES;
+    const char* bufB = bufA + TILE_BYTES;
+    if (NBUF == 2) {
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    } else {
+      issue(kt, 0);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 fx[4], fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
+        fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 64 + t * 16 + frow, ks * 4 + fch));
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
+    }
+    __syncthreads();
+  }
+  epilogue_store<T>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, act, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -199,24 +285,36 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
+static int g_gemm_variant = 0;   // 0 = register staging, 1 = direct-to-LDS (2 buffers), 2 = direct-to-LDS (1 buffer, 4 WG/CU)
+void set_gemm_variant(int v) { g_gemm_variant = v; }
+
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   const int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
-  const size_t lds = 4 * TILE_BYTES;   // 64 KiB: two workgroups per CU
+  const size_t lds = (g_gemm_variant == 2 ? 2 : 4) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
   dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(256);
-#define D3PM_GEMM(T)                                                                                          \
+#define D3PM_GEMM(...)                                                                                        \
   do {                                                                                                        \
     static bool attr_set = false;                                                                             \
     if (!attr_set) {                                                                                          \
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_128<T>),                    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),                         \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));        \
       attr_set = true;                                                                                        \
     }                                                                                                         \
-    gemm_mfma_128<T><<<grid, block, lds, s>>>(static_cast<const T*>(a.X), a.ldx, static_cast<const T*>(a.W), \
-                                              static_cast<const T*>(a.bias), static_cast<T*>(a.Y), a.ldy,     \
-                                              static_cast<const T*>(a.R1), static_cast<const T*>(a.R2), a.ldr, \
-                                              a.row_mask, a.mask_period, a.M, a.N, a.K, a.act, n_tiles);      \
+    using T = std::remove_const_t<std::remove_pointer_t<decltype(tag)>>;                                      \
+    __VA_ARGS__<<<grid, block, lds, s>>>(static_cast<const T*>(a.X), a.ldx, static_cast<const T*>(a.W),      \
+                                         static_cast<const T*>(a.bias), static_cast<T*>(a.Y), a.ldy,          \
+                                         static_cast<const T*>(a.R1), static_cast<const T*>(a.R2), a.ldr,     \
+                                         a.row_mask, a.mask_period, a.M, a.N, a.K, a.act, n_tiles);           \
   } while (0)
-  if (dtype == D3PM_F16) D3PM_GEMM(f16); else D3PM_GEMM(bf16);
+  auto go = [&](auto* tag) -> int {
+    using U = std::remove_pointer_t<decltype(tag)>;
+    if (g_gemm_variant == 1) D3PM_GEMM(gemm_mfma_128_glds<U, 2>);
+    else if (g_gemm_variant == 2) D3PM_GEMM(gemm_mfma_128_glds<U, 1>);
+    else D3PM_GEMM(gemm_mfma_128<U>);
+    return D3PM_OK;
+  };
+  int rc = dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
+  if (rc != D3PM_OK) return rc;
 #undef D3PM_GEMM
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;

@@ -75,6 +75,7 @@ SIGNATURES = {
                                     C.c_void_p]),
     "d3pm_op_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_float, C.c_void_p]),
+    "d3pm_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "d3pm_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "d3pm_prof_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double)]),
@@ -279,6 +280,10 @@ def uniform(seed: int, t: int, row0: int, rows: int, n_classes: int, stream_id: 
     out = torch.empty((rows, n_classes), dtype=torch.float32, device=device)
     check(lib().d3pm_uniform(seed, t, row0, rows, n_classes, stream_id, _p(out), stream_ptr()), "d3pm_uniform")
     return out
+
+
+def set_gemm_variant(v: int):
+    check(lib().d3pm_set_tuning(0, v), "d3pm_set_tuning")
 
 
 def prof_enable(kclass: int, max_events: int):
