@@ -43,18 +43,22 @@ def main():
         y = torch.empty(M, ldy, device=DEV, dtype=dtype)
         r = torch.randn(M, ldy, device=DEV).to(dtype) if res else None
         line = f"{name:10s} N={N:5d} K={K:5d}"
-        for variant in (0, 1, 2):
+        for variant in (2, 3):
             _hip.set_gemm_variant(variant)
             t = timeit(lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=ldy))
             line += f" | v{variant}: {t * 1e6:7.1f} us {2 * M * N * K / t / 1e12:7.1f} TF/s"
         print(line, flush=True)
-    _hip.set_gemm_variant(0)
+    _hip.set_gemm_variant(2)
     print("# attention  B=32 H=8 hd=64")
     for name, Tq, S in (("self", 768, 768), ("text", 768, 50), ("prompt", 768, 225)):
         q = torch.randn(32, Tq, 512, device=DEV).to(dtype)
         kv = torch.randn(32, S, 1024, device=DEV).to(dtype)
-        t = timeit(lambda: _hip.op_attention(q, kv[..., :512], kv[..., 512:], 8, 0.125, family=_hip.FAMILY_MFMA))
-        print(f"{name:8s} Tq={Tq} S={S:4d}: {t * 1e6:7.1f} us {4 * 32 * 8 * Tq * S * 64 / t / 1e12:7.1f} TF/s", flush=True)
+        line = f"{name:8s} Tq={Tq} S={S:4d}:"
+        for qg in (1, 2):
+            _hip.set_attn_query_groups(qg)
+            t = timeit(lambda: _hip.op_attention(q, kv[..., :512], kv[..., 512:], 8, 0.125, family=_hip.FAMILY_MFMA))
+            line += f" | qg{qg}: {t * 1e6:7.1f} us {4 * 32 * 8 * Tq * S * 64 / t / 1e12:7.1f} TF/s"
+        print(line, flush=True)
     print("# layernorm  N=24576 d=512")
     x = torch.randn(M, 512, device=DEV).to(dtype)
     w = torch.randn(512, device=DEV).to(dtype)

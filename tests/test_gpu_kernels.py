@@ -33,10 +33,27 @@ def gelu32(v):
     return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
 
 
+@pytest.fixture(params=[0, 1, 2, 3], ids=lambda v: f"gemm_v{v}")
+def gemm_variant(request, built_lib):
+    """Every staging variant of the MFMA GEMM must pass the same numerics (the default is restored afterwards)."""
+    from vall_e.vall_e import _hip
+    _hip.set_gemm_variant(request.param)
+    yield request.param
+    _hip.set_gemm_variant(2)
+
+
+@pytest.fixture(params=[1, 2], ids=lambda v: f"qg{v}")
+def attn_qg(request, built_lib):
+    from vall_e.vall_e import _hip
+    _hip.set_attn_query_groups(request.param)
+    yield request.param
+    _hip.set_attn_query_groups(2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,ldy", [(448, 512, 512, None), (1536, 1536, 512, None), (1536, 512, 2048, None),
                                        (448, 1025, 512, 1032), (200, 96, 64, None), (448, 2048, 512, None)])
-def test_linear_mfma_vs_generic_vs_torch(built_lib, dtype, M, N, K, ldy):
+def test_linear_mfma_vs_generic_vs_torch(gemm_variant, dtype, M, N, K, ldy):
     from vall_e.vall_e import _hip
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     x = (torch.randn(M, K, generator=g)).to(dtype).to(DEV)
@@ -52,7 +69,7 @@ def test_linear_mfma_vs_generic_vs_torch(built_lib, dtype, M, N, K, ldy):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_linear_epilogues(built_lib, dtype):
+def test_linear_epilogues(gemm_variant, dtype):
     """bias + exact-erf GELU; double residual with the eager rounding order; in-place residual; row mask."""
     from vall_e.vall_e import _hip
     M, N, K, T = 896, 512, 512, 448
@@ -103,7 +120,7 @@ def torch_attention(q, k, v, H, scale):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("Tq,S", [(448, 448), (448, 50), (448, 398), (768, 768), (768, 225), (128, 1), (64, 65)])
-def test_attention_mfma_vs_generic_vs_torch(built_lib, dtype, Tq, S):
+def test_attention_mfma_vs_generic_vs_torch(attn_qg, dtype, Tq, S):
     from vall_e.vall_e import _hip
     B, H, hd = 2, 8, 64
     d = H * hd

@@ -5,7 +5,7 @@
 // q*sqrt(1/hd) -> bmm -> softmax -> bmm.  The [T,S] score matrix and the head-averaged weights the
 // reference materialises (and throws away) never exist here.
 //
-// Workgroup = 4 wave64 = 64 queries of one (utterance, head); each wave owns 16 queries and walks
+// Workgroup = 4 wave64 = 64 (QG=1) or 128 (QG=2) queries of one (utterance, head); each wave owns 16*QG queries and walks
 // the keys in tiles of 64 with an online softmax.
 //   * S^T = K.Q^T by v_mfma_f32_16x16x32 (K fragment = A operand from LDS, Q fragment = B operand
 //     held in registers for the whole kernel): a lane holds 4 consecutive keys x 4 key tiles of ONE
@@ -32,7 +32,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 
-constexpr int HD = 64, BQ = 64, BKV = 64, ROWB = 128;
+constexpr int HD = 64, BKV = 64, ROWB = 128;
 constexpr int TILE = BKV * ROWB;   // 8 KiB per K or V tile
 
 template <typename T> __device__ __forceinline__ floatx4 mma(uint4 a, uint4 b, floatx4 c);
@@ -51,21 +51,22 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
   return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, x)) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, y)) << 16);
 }
 
-template <typename T>
+template <typename T, int QG>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
 __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
                                                       const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo,
                                                       int Tq, int S, float scale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE];   // [buffer][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ + wave * 16;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = (blockIdx.x * 4 + wave) * (16 * QG);
   const int qi = lane & 15, g = lane >> 4;
   const T* Kb = Kp + static_cast<size_t>(b) * S * ldkv + h * HD;
   const T* Vb = Vp + static_cast<size_t>(b) * S * ldkv + h * HD;
 
-  // Q fragment (B operand of S^T = K.Q^T): lane holds q[query qi][32*ks + 8g .. +7], pre-scaled like q*sqrt(1/hd)
-  uint4 qf[2];
-  {
-    int qrow = q0 + qi;
+  // Q fragments (B operand of S^T = K.Q^T): lane holds q[query][32*ks + 8g .. +7], pre-scaled like q*sqrt(1/hd)
+  uint4 qf[QG][2];
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    int qrow = q0 + qg * 16 + qi;
     qrow = qrow < Tq ? qrow : Tq - 1;
     const T* qp = Q + (static_cast<size_t>(b) * Tq + qrow) * ldq + h * HD;
 #pragma unroll
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
       uint32_t w[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) w[i] = pack2<T>(static_cast<float>(e[2 * i]) * scale, static_cast<float>(e[2 * i + 1]) * scale);
-      qf[ks] = uint4{w[0], w[1], w[2], w[3]};
+      qf[qg][ks] = uint4{w[0], w[1], w[2], w[3]};
     }
   }
 
@@ -111,10 +112,15 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
   store_tile(0);
   __syncthreads();
 
-  float m_run = -INFINITY, l_part = 0.f;
-  floatx4 acc_o[4];
+  float m_run[QG], l_part[QG];
+  floatx4 acc_o[QG][4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) acc_o[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int qg = 0; qg < QG; ++qg) {
+    m_run[qg] = -INFINITY;
+    l_part[qg] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc_o[qg][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
 
   for (int tile = 0; tile < n_tiles; ++tile) {
     const char* kb = smem + (tile & 1) * 2 * TILE;
@@ -122,54 +128,65 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
     const bool more = tile + 1 < n_tiles;
     if (more) load_tile(tile + 1);
 
-    // ---- S^T tile: 64 keys x 16 queries per wave ----
-    floatx4 s[4];
+    // ---- S^T tile: 64 keys x (16 QG) queries per wave; each K fragment feeds QG MFMAs ----
+    floatx4 s[QG][4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      s[kt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) s[qg][kt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         uint4 kf = *reinterpret_cast<const uint4*>(kb + k_off(kt * 16 + qi, ks * 4 + g));
-        s[kt] = mma<T>(kf, qf[ks], s[kt]);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) s[qg][kt] = mma<T>(kf, qf[qg][ks], s[qg][kt]);
+      }
+    // lane holds scores of its query for keys tile*64 + kt*16 + 4g + r
+    const int key_base = tile * BKV + 4 * g;
+    uint4 pf[QG][2];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = rn<T>(s[qg][kt][r]);
+          v = (key_base + kt * 16 + r < S) ? v : -INFINITY;
+          s[qg][kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+      const float m_new = fmaxf(m_run[qg], mx);
+      const float alpha = expf(m_run[qg] - m_new);      // exp(-inf) = 0 on the first tile
+      m_run[qg] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = rn<T>(expf(s[qg][kt][r] - m_new));
+          s[qg][kt][r] = p;
+          psum += p;
+        }
+      l_part[qg] = l_part[qg] * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc_o[qg][dt][r] *= alpha;
+      // contraction index j<4 -> key tile 2kb, j>=4 -> key tile 2kb+1 (same permutation as the V reads)
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        const floatx4 pa = s[qg][2 * kb2], pb = s[qg][2 * kb2 + 1];
+        pf[qg][kb2] = uint4{pack2<T>(pa[0], pa[1]), pack2<T>(pa[2], pa[3]), pack2<T>(pb[0], pb[1]), pack2<T>(pb[2], pb[3])};
       }
     }
-    // lane holds scores of query qi for keys tile*64 + kt*16 + 4g + r
-    float mx = -INFINITY;
-    const int key_base = tile * BKV + 4 * g;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = rn<T>(s[kt][r]);
-        v = (key_base + kt * 16 + r < S) ? v : -INFINITY;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = expf(m_run - m_new);      // exp(-inf) = 0 on the first tile
-    m_run = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float p = rn<T>(expf(s[kt][r] - m_new));
-        s[kt][r] = p;
-        psum += p;
-      }
-    l_part = l_part * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha;
 
-    // ---- O^T += V^T . P^T : contraction index j<4 -> key tile 2kb, j>=4 -> key tile 2kb+1 ----
+    // ---- O^T += V^T . P^T ; each transposed V fragment feeds QG MFMAs ----
 #pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2) {
-      const floatx4 pa = s[2 * kb2], pb = s[2 * kb2 + 1];
-      const uint4 pf = uint4{pack2<T>(pa[0], pa[1]), pack2<T>(pa[2], pa[3]), pack2<T>(pb[0], pb[1]), pack2<T>(pb[2], pb[3])};
+    for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         // 16-lane group g, lane qi: address of row (key0 + qi>>2), columns 16dt + 4(qi&3) .. +3
@@ -179,23 +196,27 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
         short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + v_off(r0, col >> 3) + (col & 7) * 2));
         short4v vc = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + v_off(r1, col >> 3) + (col & 7) * 2));
         uint2 lo = __builtin_bit_cast(uint2, va), hi = __builtin_bit_cast(uint2, vc);
-        acc_o[dt] = mma<T>(uint4{lo.x, lo.y, hi.x, hi.y}, pf, acc_o[dt]);
+        const uint4 vf = uint4{lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) acc_o[qg][dt] = mma<T>(vf, pf[qg][kb2], acc_o[qg][dt]);
       }
-    }
     if (more) store_tile((tile + 1) & 1);
     __syncthreads();
   }
 
-  float l = l_part + __shfl_xor(l_part, 16, kWave);
-  l += __shfl_xor(l, 32, kWave);
-  const float inv = 1.0f / l;
-  const int qrow = q0 + qi;
-  if (qrow < Tq) {
-    T* op = O + (static_cast<size_t>(b) * Tq + qrow) * ldo + h * HD;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      uint2 o{pack2<T>(acc_o[dt][0] * inv, acc_o[dt][1] * inv), pack2<T>(acc_o[dt][2] * inv, acc_o[dt][3] * inv)};
-      *reinterpret_cast<uint2*>(op + dt * 16 + 4 * g) = o;
+  for (int qg = 0; qg < QG; ++qg) {
+    float l = l_part[qg] + __shfl_xor(l_part[qg], 16, kWave);
+    l += __shfl_xor(l, 32, kWave);
+    const float inv = 1.0f / l;
+    const int qrow = q0 + qg * 16 + qi;
+    if (qrow < Tq) {
+      T* op = O + (static_cast<size_t>(b) * Tq + qrow) * ldo + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 o{pack2<T>(acc_o[qg][dt][0] * inv, acc_o[qg][dt][1] * inv), pack2<T>(acc_o[qg][dt][2] * inv, acc_o[qg][dt][3] * inv)};
+        *reinterpret_cast<uint2*>(op + dt * 16 + 4 * g) = o;
+      }
     }
   }
 }
@@ -211,16 +232,19 @@ bool mfma_attention_supported(int dtype, const AttnArgs& a) {
   return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 8);
 }
 
+static int g_attn_qg = 2;
+void set_attn_qg(int v) { g_attn_qg = v; }
+
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
-  dim3 grid((a.Tq + BQ - 1) / BQ, a.H, a.B), block(256);
-  if (dtype == D3PM_F16)
-    attn_mfma_hd64<f16><<<grid, block, 0, s>>>(static_cast<const f16*>(a.Q), a.ldq, static_cast<const f16*>(a.K),
-                                               static_cast<const f16*>(a.V), a.ldkv, static_cast<f16*>(a.O), a.ldo,
-                                               a.Tq, a.S, a.scale);
-  else
-    attn_mfma_hd64<bf16><<<grid, block, 0, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K),
-                                                static_cast<const bf16*>(a.V), a.ldkv, static_cast<bf16*>(a.O), a.ldo,
-                                                a.Tq, a.S, a.scale);
+  const int qg = g_attn_qg == 1 ? 1 : 2, per_block = 64 * qg;
+  dim3 grid((a.Tq + per_block - 1) / per_block, a.H, a.B), block(256);
+#define D3PM_ATTN(T, QG)                                                                                             \
+  attn_mfma_hd64<T, QG><<<grid, block, 0, s>>>(static_cast<const T*>(a.Q), a.ldq, static_cast<const T*>(a.K),        \
+                                               static_cast<const T*>(a.V), a.ldkv, static_cast<T*>(a.O), a.ldo, a.Tq, \
+                                               a.S, a.scale)
+  if (dtype == D3PM_F16) { if (qg == 1) D3PM_ATTN(f16, 1); else D3PM_ATTN(f16, 2); }
+  else { if (qg == 1) D3PM_ATTN(bf16, 1); else D3PM_ATTN(bf16, 2); }
+#undef D3PM_ATTN
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;
 }

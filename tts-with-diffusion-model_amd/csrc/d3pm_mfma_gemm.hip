@@ -45,11 +45,17 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 
 template <typename T> struct Pack4 { T v[4]; };
 
-template <typename T>
+// Epilogue on the accumulator layout D[n = nt*16 + (lane>>4)*4 + r][m = mt*16 + (lane&15)]: a lane owns 4
+// consecutive columns of one row per (mt, nt).  Residual loads are branch-free (clamped addresses) and
+// batched per row so that four 8-byte loads are in flight together; only the stores are predicated.
+// EPI bits: 1 = exact-erf GELU, 2 = one residual (R1), 4 = two residuals (R1, R2), 8 = frame mask
+constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8;
+
+template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[4][4], const T* __restrict__ bias, T* Y, int ldy,
                                                const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                               int mask_period, int M, int N, int act, int mw0, int nw0, int lane) {
-  // epilogue: lane holds D[n = nt*16 + (lane>>4)*4 + r][m = mt*16 + (lane&15)], r = 0..3
+                                               int mask_period, int M, int N, int mw0, int nw0, int lane) {
+  constexpr bool kGelu = EPI & EPI_GELU, kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
   const int nq = (lane >> 4) * 4;
   float bv[4][4];
 #pragma unroll
@@ -59,60 +65,56 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[4][4], const T* __
       const int n = nw0 + nt * 16 + nq + r;
       bv[nt][r] = (bias && n < N) ? static_cast<float>(bias[n]) : 0.f;
     }
+  const int n_last = N >= 4 ? N - 4 : 0;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = mw0 + mt * 16 + (lane & 15);
-    if (m >= M) continue;
-    const float mk = row_mask ? (row_mask[m % mask_period] ? 1.f : 0.f) : 1.f;
+    const int mc = m < M ? m : M - 1;
+    const float mk = kMask ? (row_mask[mc % mask_period] ? 1.f : 0.f) : 1.f;
+    Pack4<T> p1[4], p2[4];
+    if (kR1) {   // N % 4 == 0 is guaranteed by mfma_linear_supported when a residual is given
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        int nc = nw0 + nt * 16 + nq;
+        nc = nc < n_last ? nc : n_last;
+        p1[nt] = *reinterpret_cast<const Pack4<T>*>(R1 + static_cast<size_t>(mc) * ldr + nc);
+        if (kR2) p2[nt] = *reinterpret_cast<const Pack4<T>*>(R2 + static_cast<size_t>(mc) * ldr + nc);
+      }
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int n = nw0 + nt * 16 + nq;
-      if (n >= N) continue;
-      const bool full = n + 3 < N;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = rn<T>(acc[nt][mt][r] + bv[nt][r]);
-        if (act == ACT_GELU) v[r] = rn<T>(gelu_erf(v[r]));
-      }
-      if (R1) {
-        const T* r1 = R1 + static_cast<size_t>(m) * ldr + n;
-        const T* r2 = R2 ? R2 + static_cast<size_t>(m) * ldr + n : nullptr;
-        if (full) {
-          Pack4<T> p1 = *reinterpret_cast<const Pack4<T>*>(r1), p2{};
-          if (r2) p2 = *reinterpret_cast<const Pack4<T>*>(r2);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float res = static_cast<float>(p1.v[r]);
-            if (r2) res = rn<T>(res + static_cast<float>(p2.v[r]));
-            v[r] = rn<T>(res + v[r]);
-          }
-        } else {
-          for (int r = 0; r < 4 && n + r < N; ++r) {
-            float res = static_cast<float>(r1[r]);
-            if (r2) res = rn<T>(res + static_cast<float>(r2[r]));
-            v[r] = rn<T>(res + v[r]);
-          }
+        if (kGelu) v[r] = rn<T>(gelu_erf(v[r]));
+        if (kR1) {
+          float res = static_cast<float>(p1[nt].v[r]);
+          if (kR2) res = rn<T>(res + static_cast<float>(p2[nt].v[r]));
+          v[r] = rn<T>(res + v[r]);
         }
       }
-      T* y = Y + static_cast<size_t>(m) * ldy + n;
-      if (full) {
-        Pack4<T> o;
+      if (m < M && n < N) {
+        T* y = Y + static_cast<size_t>(m) * ldy + n;
+        if (n + 3 < N) {
+          Pack4<T> o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o.v[r] = static_cast<T>(v[r] * mk);
-        *reinterpret_cast<Pack4<T>*>(y) = o;
-      } else {
-        for (int r = 0; r < 4 && n + r < N; ++r) y[r] = static_cast<T>(v[r] * mk);
+          for (int r = 0; r < 4; ++r) o.v[r] = static_cast<T>(v[r] * mk);
+          *reinterpret_cast<Pack4<T>*>(y) = o;
+        } else {
+          for (int r = 0; r < 4 && n + r < N; ++r) y[r] = static_cast<T>(v[r] * mk);
+        }
       }
     }
   }
 }
 
-template <typename T>
+template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_128(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                         const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                         const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                                        int mask_period, int M, int N, int K, int act, int n_tiles) {
+                                                        int mask_period, int M, int N, int K, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128(const T* __restrict__ X,
     __syncthreads();
   }
 
-  epilogue_store<T>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, act, m0 + wm * 64, n0 + wn * 64, lane);
+  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 
@@ -200,11 +202,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128(const T* __restrict__ X,
 typedef __attribute__((address_space(3))) void* lds_void;
 typedef const __attribute__((address_space(1))) void* glb_void;
 
-template <typename T, int NBUF>   // NBUF 2: next tile's DMA issued before the MFMAs; NBUF 1: 32 KiB LDS, 4 workgroups per CU
+template <typename T, int EPI, int NBUF>   // NBUF 2: next tile's DMA issued before the MFMAs; NBUF 1: 32 KiB LDS, 4 workgroups per CU
 __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_mfma_128_glds(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                              const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                              const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                                             int mask_period, int M, int N, int K, int act, int n_tiles) {
+                                                             int mask_period, int M, int N, int K, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -268,7 +270,95 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_mfma_128_glds(con
     }
     __syncthreads();
   }
-  epilogue_store<T>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, act, m0 + wm * 64, n0 + wn * 64, lane);
+  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+
+// ---- variant 3: direct-to-LDS staging issued from inline asm, next tile in flight under the MFMAs ------
+// hipcc cannot tell an in-flight LDS-DMA from the LDS reads of the tile being computed and drains it
+// (vmcnt(0)) before the first ds_read; issuing the DMA from asm keeps it out of the compiler's counters, so
+// the wait is placed by hand: counted vmcnt (8 DMAs per wave per tile stay in flight), raw s_barrier.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_128_pf(const T* __restrict__ X, int ldx, const T* __restrict__ W,
+                                                           const T* __restrict__ bias, T* Y, int ldy, const T* R1,
+                                                           const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
+                                                           int mask_period, int M, int N, int K, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) char*)smem));
+
+  const T* gx[4];
+  const T* gw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    int mr = m0 + row, nr = n0 + row;
+    mr = mr < M ? mr : M - 1;
+    nr = nr < N ? nr : N - 1;
+    gx[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
+    gw[i] = W + static_cast<size_t>(nr) * K + logical * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+    const uint32_t base = lds_base + buf * 2 * TILE_BYTES + (wave * 4) * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16_asm(gx[i] + kt * BK, base + i * 1024);
+      glds16_asm(gw[i] + kt * BK, base + TILE_BYTES + i * 1024);
+    }
+  };
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  const int nk = K / BK;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* bufA = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* bufB = bufA + TILE_BYTES;
+    if (kt + 1 < nk) {
+      issue(kt + 1, (kt + 1) & 1);                       // buffer last read in iteration kt-1 (barrier B below)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's 8 DMAs of tile kt have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                        // barrier A: every wave's share of tile kt is in LDS
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 fx[4], fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
+        fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 64 + t * 16 + frow, ks * 4 + fch));
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of tile kt retired
+    __builtin_amdgcn_s_barrier();                        // barrier B: tile kt's buffer may be overwritten
+  }
+  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -279,40 +369,62 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
   if (a.M < 1 || a.N < 1 || a.K < BK || a.K % BK != 0) return false;
   if (a.ldx % 8 != 0 || a.ldy % 4 != 0 || !aligned(a.X, 16) || !aligned(a.W, 16) || !aligned(a.Y, 8)) return false;
-  if (a.R1 && (a.ldr % 4 != 0 || !aligned(a.R1, 8))) return false;
+  if (a.R1 && (a.ldr % 4 != 0 || a.N % 4 != 0 || !aligned(a.R1, 8))) return false;
   if (a.R2 && !aligned(a.R2, 8)) return false;
   if (static_cast<long long>(a.M) * a.N < 128 * 128) return false;     // not worth a 128^2 tile
+  const bool gelu = a.act == ACT_GELU, r1 = a.R1 != nullptr, r2 = a.R2 != nullptr, mk = a.row_mask != nullptr;
+  if (a.act != ACT_NONE && !gelu) return false;
+  if (r2 && !r1) return false;
+  // instantiated epilogues: plain, GELU, R1, R1+R2, R1+mask
+  if (gelu && (r1 || mk)) return false;
+  if (mk && (!r1 || r2)) return false;
   return true;
 }
 
-static int g_gemm_variant = 0;   // 0 = register staging, 1 = direct-to-LDS (2 buffers), 2 = direct-to-LDS (1 buffer, 4 WG/CU)
+static int g_gemm_variant = 2;   // 0 register staging, 1 direct-to-LDS 2 buffers, 2 direct-to-LDS 1 buffer (4 WG/CU), 3 asm DMA prefetch
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   const int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
-  const size_t lds = (g_gemm_variant == 2 ? 2 : 4) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
+  const int variant = g_gemm_variant;
+  const size_t lds = (variant == 2 ? 2 : 4) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
   dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(256);
-#define D3PM_GEMM(...)                                                                                        \
-  do {                                                                                                        \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),                         \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));        \
-      attr_set = true;                                                                                        \
-    }                                                                                                         \
-    using T = std::remove_const_t<std::remove_pointer_t<decltype(tag)>>;                                      \
-    __VA_ARGS__<<<grid, block, lds, s>>>(static_cast<const T*>(a.X), a.ldx, static_cast<const T*>(a.W),      \
-                                         static_cast<const T*>(a.bias), static_cast<T*>(a.Y), a.ldy,          \
-                                         static_cast<const T*>(a.R1), static_cast<const T*>(a.R2), a.ldr,     \
-                                         a.row_mask, a.mask_period, a.M, a.N, a.K, a.act, n_tiles);           \
+  const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
+
+#define D3PM_GEMM(...)                                                                                          \
+  do {                                                                                                          \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),                           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));          \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    __VA_ARGS__<<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),        \
+                                         static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,            \
+                                         static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr,       \
+                                         a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles);                    \
+    return D3PM_OK;                                                                                             \
+  } while (0)
+#define D3PM_GEMM_EPI(E)                                                        \
+  do {                                                                          \
+    if (variant == 3) D3PM_GEMM(gemm_mfma_128_pf<U, E>);                        \
+    else if (variant == 2) D3PM_GEMM(gemm_mfma_128_glds<U, E, 1>);              \
+    else if (variant == 1) D3PM_GEMM(gemm_mfma_128_glds<U, E, 2>);              \
+    else D3PM_GEMM(gemm_mfma_128<U, E>);                                        \
   } while (0)
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
-    if (g_gemm_variant == 1) D3PM_GEMM(gemm_mfma_128_glds<U, 2>);
-    else if (g_gemm_variant == 2) D3PM_GEMM(gemm_mfma_128_glds<U, 1>);
-    else D3PM_GEMM(gemm_mfma_128<U>);
-    return D3PM_OK;
+    switch (epi) {   // the epilogues the denoiser uses
+      case 0: D3PM_GEMM_EPI(0);
+      case EPI_GELU: D3PM_GEMM_EPI(EPI_GELU);
+      case EPI_R1: D3PM_GEMM_EPI(EPI_R1);
+      case EPI_R2: D3PM_GEMM_EPI(EPI_R2);
+      case EPI_R1 | EPI_MASK: D3PM_GEMM_EPI(EPI_R1 | EPI_MASK);
+      default: break;
+    }
+    return D3PM_E_SHAPE;
   };
+#undef D3PM_GEMM_EPI
   int rc = dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
   if (rc != D3PM_OK) return rc;
 #undef D3PM_GEMM

@@ -286,6 +286,10 @@ def set_gemm_variant(v: int):
     check(lib().d3pm_set_tuning(0, v), "d3pm_set_tuning")
 
 
+def set_attn_query_groups(v: int):
+    check(lib().d3pm_set_tuning(1, v), "d3pm_set_tuning")
+
+
 def prof_enable(kclass: int, max_events: int):
     check(lib().d3pm_prof_enable(kclass, max_events), "d3pm_prof_enable")
 
