@@ -18,10 +18,13 @@
 //   * K and V tiles are staged global -> registers -> LDS (16 B per lane) one tile ahead, one
 //     barrier per tile; 128-B LDS rows, 16-B chunks XOR-swizzled (K: (row>>1)&7 for the b128
 //     fragment reads, V: ((row>>1)&3)<<1 for the transposed reads) -- conflict-free by construction.
-// Numerics: scores are rounded to the storage dtype like the eager bmm output; the probabilities
-// enter the second MFMA un-normalised (e^(s-m) <= 1, rounded to the storage dtype) and the sum is
-// divided out in fp32 at the end -- this differs from the eager softmax->round->bmm chain by
-// rounding noise only and is what the MFMA family is allowed to do (precision modes).
+// Numerics (flash-style, NOT the eager rounding points -- the generic attention_rows keeps those): scores stay
+// fp32 in the log2 domain, the probabilities enter the second MFMA un-normalised (2^(s-m) <= 1, rounded to
+// the storage dtype), the row sum is accumulated in fp32 and divided out at the end.  Differs from the eager
+// round(bmm) -> softmax -> round -> bmm chain by rounding noise only (precision modes).
+// The softmax is VALU-bound at head_dim 64 (256 flop of MFMA per score), so it is kept to ~6 VALU issue
+// slots per score: max, sub, v_exp_f32, add, half a cvt_pk; the O rescale is skipped when no maximum moved
+// and the key-padding compare/select only runs on a ragged last tile.
 #include "d3pm_kernels.h"
 
 namespace d3pm {
@@ -62,7 +65,9 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
   const T* Kb = Kp + static_cast<size_t>(b) * S * ldkv + h * HD;
   const T* Vb = Vp + static_cast<size_t>(b) * S * ldkv + h * HD;
 
-  // Q fragments (B operand of S^T = K.Q^T): lane holds q[query][32*ks + 8g .. +7], pre-scaled like q*sqrt(1/hd)
+  // Q fragments (B operand of S^T = K.Q^T): lane holds q[query][32*ks + 8g .. +7], pre-scaled by
+  // sqrt(1/hd) * log2(e) so that the scores come out of the MFMA in the log2 domain (softmax via v_exp_f32)
+  const float qscale = scale * 1.4426950408889634f;
   uint4 qf[QG][2];
 #pragma unroll
   for (int qg = 0; qg < QG; ++qg) {
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
       const T* e = reinterpret_cast<const T*>(&raw);
       uint32_t w[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = pack2<T>(static_cast<float>(e[2 * i]) * scale, static_cast<float>(e[2 * i + 1]) * scale);
+      for (int i = 0; i < 4; ++i) w[i] = pack2<T>(static_cast<float>(e[2 * i]) * qscale, static_cast<float>(e[2 * i + 1]) * qscale);
       qf[qg][ks] = uint4{w[0], w[1], w[2], w[3]};
     }
   }
@@ -142,40 +147,43 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) s[qg][kt] = mma<T>(kf, qf[qg][ks], s[qg][kt]);
       }
-    // lane holds scores of its query for keys tile*64 + kt*16 + 4g + r
+    // lane holds scores (log2 domain) of its query for keys tile*64 + kt*16 + 4g + r
+    const bool ragged = (tile == n_tiles - 1) && (S & (BKV - 1));   // wave-uniform: only the last tile can be partial
     const int key_base = tile * BKV + 4 * g;
     uint4 pf[QG][2];
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
-      float mx = -INFINITY;
+      if (ragged) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = rn<T>(s[qg][kt][r]);
-          v = (key_base + kt * 16 + r < S) ? v : -INFINITY;
-          s[qg][kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
+          for (int r = 0; r < 4; ++r) s[qg][kt][r] = (key_base + kt * 16 + r < S) ? s[qg][kt][r] : -INFINITY;
+      }
+      float mx = fmaxf(fmaxf(s[qg][0][0], s[qg][0][1]), fmaxf(s[qg][0][2], s[qg][0][3]));
+#pragma unroll
+      for (int kt = 1; kt < 4; ++kt)
+        mx = fmaxf(mx, fmaxf(fmaxf(s[qg][kt][0], s[qg][kt][1]), fmaxf(s[qg][kt][2], s[qg][kt][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
       mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
       const float m_new = fmaxf(m_run[qg], mx);
-      const float alpha = expf(m_run[qg] - m_new);      // exp(-inf) = 0 on the first tile
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);      // exp2(-inf) = 0 on the first tile
       m_run[qg] = m_new;
       float psum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = rn<T>(expf(s[qg][kt][r] - m_new));
+          const float p = __builtin_amdgcn_exp2f(s[qg][kt][r] - m_new);
           s[qg][kt][r] = p;
           psum += p;
         }
       l_part[qg] = l_part[qg] * alpha + psum;
+      if (!__all(alpha == 1.0f)) {                       // the running max moved for some query of this wave
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc_o[qg][dt][r] *= alpha;
+          for (int r = 0; r < 4; ++r) acc_o[qg][dt][r] *= alpha;
+      }
       // contraction index j<4 -> key tile 2kb, j>=4 -> key tile 2kb+1 (same permutation as the V reads)
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {

@@ -45,6 +45,14 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 
 template <typename T> struct Pack4 { T v[4]; };
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap the linear block
+// id so that each XCD walks a contiguous range of tiles: the n-tiles of one 128-row X panel then hit the same
+// L2 instead of fetching the panel from the Infinity Cache 8 times.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // Epilogue on the accumulator layout D[n = nt*16 + (lane>>4)*4 + r][m = mt*16 + (lane&15)]: a lane owns 4
 // consecutive columns of one row per (mt, nt).  Residual loads are branch-free (clamped addresses) and
 // batched per row so that four 8-byte loads are in flight together; only the stores are predicated.
@@ -118,7 +126,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128(const T* __restrict__ X,
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // staging assignment: 4 x 16 B of the X tile and 4 x 16 B of the W tile per thread
@@ -210,7 +219,8 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_mfma_128_glds(con
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const T* gx[4];
@@ -295,7 +305,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128_pf(const T* __restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) char*)smem));
