@@ -1,0 +1,48 @@
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection.csv files (two separate passes, as
+MI355X_MICROARCH.md prescribes: FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2) into per-launch
+L2-miss traffic per kernel class.  gfx950 corrections of that guide: both counters are in KiB;
+FETCH_SIZE reports exactly half of the bytes of wide coalesced streaming reads -> doubled.
+
+    python profiles/summarize_pmc.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > profiles/<name>.json
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+CLASSES = {"gemm": "gemm_mfma", "attention": "attn_mfma", "layernorm": "layernorm", "sample": "posterior_sample",
+           "embed": "embed_rows"}
+
+
+def load(directory, counter):
+    path = glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True)[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        for cls, needle in CLASSES.items():
+            if needle in r["Kernel_Name"]:
+                agg[cls][0] += 1
+                agg[cls][1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for cls in CLASSES:
+        if fetch[cls][0] == 0:
+            continue
+        f = fetch[cls][1] / fetch[cls][0] * 1024.0
+        w = write[cls][1] / max(write[cls][0], 1) * 1024.0
+        out[cls] = {"launches_profiled": fetch[cls][0], "fetch_bytes_per_launch_raw": f,
+                    "fetch_bytes_per_launch_corrected": 2.0 * f, "write_bytes_per_launch": w,
+                    "traffic_bytes_per_launch": 2.0 * f + w}
+    out["_method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1 "
+                      "--warmup 0 --profile-iters 3 (B=32 libritts bf16); KiB -> bytes; FETCH_SIZE x2 (gfx950)")
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -76,45 +76,41 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
     const T* qp = Q + (static_cast<size_t>(b) * Tq + qrow) * ldq + h * HD;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      uint4 raw = *reinterpret_cast<const uint4*>(qp + ks * 32 + g * 8);
-      const T* e = reinterpret_cast<const T*>(&raw);
-      uint32_t w[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = pack2<T>(static_cast<float>(e[2 * i]) * qscale, static_cast<float>(e[2 * i + 1]) * qscale);
-      qf[qg][ks] = uint4{w[0], w[1], w[2], w[3]};
+      typedef T tvec8 __attribute__((ext_vector_type(8)));
+      const tvec8 e = __builtin_bit_cast(tvec8, *reinterpret_cast<const uint4*>(qp + ks * 32 + g * 8));
+      qf[qg][ks] = uint4{pack2<T>(static_cast<float>(e[0]) * qscale, static_cast<float>(e[1]) * qscale),
+                         pack2<T>(static_cast<float>(e[2]) * qscale, static_cast<float>(e[3]) * qscale),
+                         pack2<T>(static_cast<float>(e[4]) * qscale, static_cast<float>(e[5]) * qscale),
+                         pack2<T>(static_cast<float>(e[6]) * qscale, static_cast<float>(e[7]) * qscale)};
     }
   }
 
-  // staging: thread -> 2 x 16 B of the K tile and 2 x 16 B of the V tile
-  int srow[2], sch[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int c = tid + 256 * i;
-    srow[i] = c >> 3;
-    sch[i] = c & 7;
-  }
-  uint4 rk[2], rv[2];
-  auto load_tile = [&](int tile) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key = tile * BKV + srow[i];
-      key = key < S ? key : S - 1;
-      rk[i] = *reinterpret_cast<const uint4*>(Kb + static_cast<size_t>(key) * ldkv + sch[i] * 8);
-      rv[i] = *reinterpret_cast<const uint4*>(Vb + static_cast<size_t>(key) * ldkv + sch[i] * 8);
-    }
+  // staging: thread -> 2 x 16 B of the K tile and 2 x 16 B of the V tile (rows r0s and r0s+32, chunk chs);
+  // plain scalars / by-value struct so that the in-flight tile lives in VGPRs, not in scratch
+  const int r0s = tid >> 3, chs = tid & 7;
+  const int ko0 = k_off(r0s, chs), ko1 = k_off(r0s + 32, chs), vo0 = v_off(r0s, chs), vo1 = v_off(r0s + 32, chs);
+  struct Staged { uint4 k0, k1, v0, v1; };
+  auto load_tile = [=](int tile) -> Staged {
+    int a = tile * BKV + r0s, c = a + 32;
+    a = a < S ? a : S - 1;
+    c = c < S ? c : S - 1;
+    Staged st;
+    st.k0 = *reinterpret_cast<const uint4*>(Kb + static_cast<size_t>(a) * ldkv + chs * 8);
+    st.k1 = *reinterpret_cast<const uint4*>(Kb + static_cast<size_t>(c) * ldkv + chs * 8);
+    st.v0 = *reinterpret_cast<const uint4*>(Vb + static_cast<size_t>(a) * ldkv + chs * 8);
+    st.v1 = *reinterpret_cast<const uint4*>(Vb + static_cast<size_t>(c) * ldkv + chs * 8);
+    return st;
   };
-  auto store_tile = [&](int buf) {
-    char* base = smem + buf * 2 * TILE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<uint4*>(base + k_off(srow[i], sch[i])) = rk[i];
-      *reinterpret_cast<uint4*>(base + TILE + v_off(srow[i], sch[i])) = rv[i];
-    }
+  auto store_tile = [=](char* base, const Staged& st) {
+    *reinterpret_cast<uint4*>(base + ko0) = st.k0;
+    *reinterpret_cast<uint4*>(base + ko1) = st.k1;
+    *reinterpret_cast<uint4*>(base + TILE + vo0) = st.v0;
+    *reinterpret_cast<uint4*>(base + TILE + vo1) = st.v1;
   };
 
   const int n_tiles = (S + BKV - 1) / BKV;
-  load_tile(0);
-  store_tile(0);
+  Staged st = load_tile(0);
+  store_tile(smem, st);
   __syncthreads();
 
   float m_run[QG], l_part[QG];
@@ -131,7 +127,7 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
     const char* kb = smem + (tile & 1) * 2 * TILE;
     const char* vb = kb + TILE;
     const bool more = tile + 1 < n_tiles;
-    if (more) load_tile(tile + 1);
+    if (more) st = load_tile(tile + 1);
 
     // ---- S^T tile: 64 keys x (16 QG) queries per wave; each K fragment feeds QG MFMAs ----
     floatx4 s[QG][4];
@@ -208,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) acc_o[qg][dt] = mma<T>(vf, pf[qg][kb2], acc_o[qg][dt]);
       }
-    if (more) store_tile((tile + 1) & 1);
+    if (more) store_tile(smem + ((tile + 1) & 1) * 2 * TILE, st);
     __syncthreads();
   }
 

@@ -372,6 +372,82 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128_pf(const T* __restrict__
   epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+
+// ---- variants 4/5: larger workgroup tiles (WGM x WGN waves of 64 x 64) -------------------------------
+// L2 -> LDS operand traffic per flop scales with (1/BM + 1/BN); at 128 x 128 it is the first-order limiter
+// (a CU takes in ~70-135 GB/s from its XCD's L2).  Same single-buffer direct-to-LDS structure as variant 2.
+template <typename T, int EPI, int WGM, int WGN, int MINW>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_mfma_big(const T* __restrict__ X, int ldx,
+                                                                     const T* __restrict__ W,
+                                                                     const T* __restrict__ bias, T* Y, int ldy,
+                                                                     const T* R1, const T* R2, int ldr,
+                                                                     const uint8_t* __restrict__ row_mask,
+                                                                     int mask_period, int M, int N, int K, int n_tiles) {
+  constexpr int TBM = 64 * WGM, TBN = 64 * WGN, NW = WGM * WGN;
+  constexpr int A_BYTES = TBM * ROW_BYTES;
+  constexpr int A_INSTR = TBM / 8, B_INSTR = TBN / 8, PER_WAVE = (A_INSTR + B_INSTR) / NW;
+  static_assert((A_INSTR + B_INSTR) % NW == 0, "staging instructions must divide evenly over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+
+  // wave-instruction j (0 .. A_INSTR+B_INSTR-1) stages 8 rows: j < A_INSTR from X, else from W
+  const T* gsrc[PER_WAVE];
+  int ldst[PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int j = wave * PER_WAVE + i;
+    const bool isA = j < A_INSTR;
+    const int row = (isA ? j : j - A_INSTR) * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    if (isA) {
+      int mr = m0 + row;
+      mr = mr < M ? mr : M - 1;
+      gsrc[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
+    } else {
+      int nr = n0 + row;
+      nr = nr < N ? nr : N - 1;
+      gsrc[i] = W + static_cast<size_t>(nr) * K + logical * 8;
+    }
+    ldst[i] = (isA ? 0 : A_BYTES) + (isA ? j : j - A_INSTR) * 1024;
+  }
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  const int nk = K / BK;
+  const char* bufA = smem;
+  const char* bufB = smem + A_BYTES;
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void)(gsrc[i] + kt * BK), (lds_void)(smem + ldst[i]), 16, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 fx[4], fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
+        fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 64 + t * 16 + frow, ks * 4 + fch));
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
+    }
+    __syncthreads();
+  }
+  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -396,10 +472,12 @@ static int g_gemm_variant = 2;   // 0 register staging, 1 direct-to-LDS 2 buffer
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
-  const int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
   const int variant = g_gemm_variant;
-  const size_t lds = (variant == 2 ? 2 : 4) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
-  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(256);
+  const int tbm = variant >= 4 ? 256 : BM, tbn = variant == 5 ? 256 : BN;
+  const int n_tiles = (a.N + tbn - 1) / tbn, m_tiles = (a.M + tbm - 1) / tbm;
+  const size_t lds = variant >= 4 ? static_cast<size_t>(tbm + tbn) * ROW_BYTES
+                                  : (variant == 2 ? 2 : 4) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
+  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(variant == 5 ? 1024 : (variant == 4 ? 512 : 256));
   const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
 
 #define D3PM_GEMM(...)                                                                                          \
@@ -418,7 +496,9 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   } while (0)
 #define D3PM_GEMM_EPI(E)                                                        \
   do {                                                                          \
-    if (variant == 3) D3PM_GEMM(gemm_mfma_128_pf<U, E>);                        \
+    if (variant == 5) D3PM_GEMM(gemm_mfma_big<U, E, 4, 4, 4>);                  \
+    else if (variant == 4) D3PM_GEMM(gemm_mfma_big<U, E, 4, 2, 4>);             \
+    else if (variant == 3) D3PM_GEMM(gemm_mfma_128_pf<U, E>);                   \
     else if (variant == 2) D3PM_GEMM(gemm_mfma_128_glds<U, E, 1>);              \
     else if (variant == 1) D3PM_GEMM(gemm_mfma_128_glds<U, E, 2>);              \
     else D3PM_GEMM(gemm_mfma_128<U, E>);                                        \
