@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-steps", type=int, default=4, help="diffusion iterations timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket GEMM launches with HIP events (roofline.achieved is then 0): measures what the "
+                         "event pairs cost the timed region")
     ap.add_argument("--profile-iters", type=int, default=0,
                     help="PROFILING ONLY: run this many diffusion iterations instead of all 99 (the JSON line is then "
                          "marked invalid_for_headline)")
@@ -66,6 +69,21 @@ def host_cores() -> int:
     except (OSError, ValueError):
         pass
     return max(1, min(n, 64))
+
+
+def pmc_traffic(kernel_class="gemm"):
+    """HBM-side bytes per launch of the dominant kernel from the most recent committed rocprofv3 PMC summary
+    (profiles/*pmc_traffic.json, produced by profiles/summarize_pmc.py from separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE passes over this same script: counters cannot be collected from inside the timed run)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        data = json.load(open(files[-1]))
+        return data[kernel_class]["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def cpu_baseline(cfg, sd32, texts, proms, n_iters):
@@ -140,13 +158,14 @@ def main():
         note(f"warmup {i + 1}/{args.warmup} done")
     fence()
     iters = args.profile_iters or (cfg.timesteps - 1)
-    _hip.prof_enable(_hip.K_GEMM, args.steps * iters * (cfg.n_layers * 9 + 1) + 64)
+    if not args.no_kernel_events:
+        _hip.prof_enable(_hip.K_GEMM, args.steps * iters * (cfg.n_layers * 9 + 1) + 64)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    launches, gemm_ms, gemm_flops, _ = _hip.prof_read()
+    launches, gemm_ms, gemm_flops, gemm_bytes = _hip.prof_read()
     _hip.prof_disable()
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -171,9 +190,13 @@ def main():
     if rank == 0:
         key = args.dtype
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        result["roofline"] = {"bound": "mfma", "kernel": "linear (all DiT GEMM launches of the timed region)",
+        traffic, traffic_src = pmc_traffic("gemm") if args.config == "libritts" and batch == 32 else (None, None)
+        result["roofline"] = {"bound": "mfma", "kernel": "gemm_mfma (all DiT GEMM launches of the timed region)",
                               "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[key], "unit": "TFLOP/s",
-                              "frac": achieved / MFMA_PEAK_TFLOPS[key], "traffic": None,
+                              "frac": achieved / MFMA_PEAK_TFLOPS[key], "traffic": traffic,
+                              "traffic_unit": "bytes/launch (L2 fabric-side, rocprofv3 PMC)", "traffic_source": traffic_src,
+                              "algorithmic_bytes_per_launch": gemm_bytes / max(launches, 1),
+                              "algorithmic_flops_per_launch": gemm_flops / max(launches, 1),
                               "launches": launches, "avg_launch_us": gemm_ms * 1e3 / max(launches, 1),
                               "gemm_share_of_step": gemm_ms / (ms_per_step * args.steps)}
         whole = algorithmic_flops_per_step(cfg, batch) * iters / (cfg.timesteps - 1) / (ms_per_step * 1e-3) / 1e12

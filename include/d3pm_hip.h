@@ -181,7 +181,7 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *                         2 direct-to-LDS single buffer, 4 workgroups per CU (default),
  *                         3 direct-to-LDS issued from asm with the next K-tile in flight under the MFMAs,
  *                         4 / 5 = variant 2 with 256x128 / 256x256 workgroup tiles (8 / 16 waves). */
-enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1 /* 16-query groups per wave: 1 or 2 (default) */ };
+enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1 /* 16-query groups per wave: 1 (default) or 2 */ };
 int d3pm_set_tuning(int knob, int value);
 
 /* Timing hooks for bench.py's roofline object: when enabled, every launch of the kernel class

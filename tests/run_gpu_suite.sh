@@ -9,6 +9,7 @@ for st in $STAGES; do
     parity)  timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_parity.log 2>&1; rc=$?; tail -25 gpurun_out/pytest_parity.log;;
     smoke)   timeout -k 10 180 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; rc=$?; tail -3 gpurun_out/smoke.log;;
     bench)   timeout -k 10 900 python bench.py --steps 2 --warmup 1 2> gpurun_out/bench.err | tee gpurun_out/bench.json; rc=${PIPESTATUS[0]}; tail -5 gpurun_out/bench.err;;
+    noev)    timeout -k 10 600 python bench.py --steps 2 --warmup 1 --no-kernel-events --cpu-steps 0 --no-latency 2> gpurun_out/bench_noev.err | tee gpurun_out/bench_noev.json; rc=${PIPESTATUS[0]};;
     micro)   timeout -k 10 600 python tests/bench_kernels.py > gpurun_out/kernels.txt 2> gpurun_out/kernels.err; rc=$?; cat gpurun_out/kernels.txt;;
     pmc)     cd /tmp && export TMPDIR=/tmp; rc=0
              for c in FETCH_SIZE WRITE_SIZE; do

@@ -159,11 +159,19 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     D3PM_TRY(run_layernorm(dt, ln, flags, s));
     char* q_text = ws.qkv;
     char* q_prom = at(ws.qkv, static_cast<size_t>(n) * d, es);
-    for (int which = 0; which < 2; ++which) {
+    if (ws.h2 == at(ws.h, static_cast<size_t>(n) * d, es)) {
+      // both query projections share cross_attn's q rows: LN2|LN22 outputs and q_text|q_prompt are adjacent in
+      // the workspace, so the pair is ONE [2n, d] x [d, d] GEMM (twice the workgroups of either alone)
       g = LinearArgs();
-      g.X = which ? ws.h2 : ws.h; g.ldx = d; g.W = b.cross_in_w; g.bias = b.cross_in_b;
-      g.Y = which ? q_prom : q_text; g.ldy = d; g.M = n; g.N = d; g.K = d;
+      g.X = ws.h; g.ldx = d; g.W = b.cross_in_w; g.bias = b.cross_in_b; g.Y = q_text; g.ldy = d; g.M = 2 * n; g.N = d; g.K = d;
       D3PM_TRY(run_linear(dt, g, flags, s));
+    } else {
+      for (int which = 0; which < 2; ++which) {
+        g = LinearArgs();
+        g.X = which ? ws.h2 : ws.h; g.ldx = d; g.W = b.cross_in_w; g.bias = b.cross_in_b;
+        g.Y = which ? q_prom : q_text; g.ldy = d; g.M = n; g.N = d; g.K = d;
+        D3PM_TRY(run_linear(dt, g, flags, s));
+      }
     }
     for (int which = 0; which < 2; ++which) {
       const int S = which ? sh.s_prompt : sh.s_text;
