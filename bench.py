@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-steps", type=int, default=4, help="diffusion iterations timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="independent batch chunks on separate HIP streams")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket GEMM launches with HIP events (roofline.achieved is then 0): measures what the "
                          "event pairs cost the timed region")
@@ -138,6 +139,7 @@ def main():
     model = AR.from_config(cfg)
     model.load_state_dict(sd32)
     model = model.to(dtype).to(dev)
+    model.loop_streams = args.streams
     texts, proms = synth.make_inputs(cfg, batch * world, 1)
     texts = [t.to(dev) for t in texts]
     proms = [p.to(dev) for p in proms]
@@ -183,7 +185,8 @@ def main():
         "config": {"workload": f"{args.config}: d={cfg.d_model} H={cfg.n_heads} L={cfg.n_layers} "
                                f"T={cfg.n_frames}/{cfg.canvas} S_text={cfg.s_text} S_prompt={cfg.s_prompt} "
                                f"{iters} diffusion iterations, n_q=1",
-                   "utterances_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}"},
+                   "utterances_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
+                   "streams_per_gpu": args.streams},
     }
     if args.profile_iters:
         result["invalid_for_headline"] = f"profiling run: {iters} of {cfg.timesteps - 1} diffusion iterations"

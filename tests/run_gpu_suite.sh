@@ -10,6 +10,7 @@ for st in $STAGES; do
     smoke)   timeout -k 10 180 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; rc=$?; tail -3 gpurun_out/smoke.log;;
     bench)   timeout -k 10 900 python bench.py --steps 2 --warmup 1 2> gpurun_out/bench.err | tee gpurun_out/bench.json; rc=${PIPESTATUS[0]}; tail -5 gpurun_out/bench.err;;
     noev)    timeout -k 10 600 python bench.py --steps 2 --warmup 1 --no-kernel-events --cpu-steps 0 --no-latency 2> gpurun_out/bench_noev.err | tee gpurun_out/bench_noev.json; rc=${PIPESTATUS[0]};;
+    streams) rc=0; for k in 1 2 4; do timeout -k 10 300 python bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-latency --streams $k 2>> gpurun_out/bench_streams.err | tee -a gpurun_out/bench_streams.json || rc=$?; done;;
     micro)   timeout -k 10 600 python tests/bench_kernels.py > gpurun_out/kernels.txt 2> gpurun_out/kernels.err; rc=$?; cat gpurun_out/kernels.txt;;
     pmc)     cd /tmp && export TMPDIR=/tmp; rc=0
              for c in FETCH_SIZE WRITE_SIZE; do

@@ -255,6 +255,8 @@ def test_batch_is_independent_runs(n16):
         assert torch.equal(both[b], one), b
     again = n16.model.generate_audio(texts, proms, steps=12, seed=5, utt0=4).cpu()
     assert torch.equal(both, again)
+    chunked = n16.model.generate_audio(texts, proms, steps=12, seed=5, utt0=4, streams=2).cpu()   # 2 HIP streams
+    assert torch.equal(both, chunked)
     assert not torch.equal(both[0], both[2])      # same inputs, different noise rows
 
 

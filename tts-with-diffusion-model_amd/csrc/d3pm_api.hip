@@ -33,6 +33,8 @@ struct Prof {
   std::vector<hipEvent_t> ev;   // pairs
   int used = 0;
   double flops = 0, bytes = 0;
+  int stride = 8;        // only the iterations with t % stride == 0 are bracketed (event pairs cost ~3 us each)
+  bool sample_now = true;
 };
 static Prof g_prof;
 
@@ -40,7 +42,7 @@ struct ProfScope {
   bool on;
   hipStream_t s;
   ProfScope(int kclass, hipStream_t st, double flops, double bytes) : s(st) {
-    on = g_prof.kclass == kclass && g_prof.used + 2 <= static_cast<int>(g_prof.ev.size());
+    on = g_prof.kclass == kclass && g_prof.sample_now && g_prof.used + 2 <= static_cast<int>(g_prof.ev.size());
     if (on) {
       (void)hipEventRecord(g_prof.ev[g_prof.used], s);
       g_prof.flops += flops;
@@ -317,6 +319,7 @@ int d3pm_sample_loop(const d3pm_shape* sh, const d3pm_weights* w, int batch, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int rows = batch * sh->canvas;
   for (int t = t_start; t > t_stop; --t) {
+    g_prof.sample_now = (t % g_prof.stride) == 0;
     D3PM_TRY(denoiser_blocks(*sh, *w, batch, x, frame_mask, t, film, kv_text, kv_prompt, ws, sh->n_layers, flags, s));
     D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, logits_ld(*sh), flags, s));
     SampleArgs a;
@@ -331,6 +334,7 @@ int d3pm_sample_loop(const d3pm_shape* sh, const d3pm_weights* w, int batch, int
       D3PM_TRY(posterior_sample(a, s));
     }
   }
+  g_prof.sample_now = true;
   return D3PM_OK;
 }
 

@@ -179,18 +179,20 @@ class Sampler:
         self.shape = make_shape(cfg, dtype)
         self.weights = DeviceWeights(tensors, cfg.n_layers)
         self.schedule = Schedule(cfg.timesteps)
-        self._ws = None
+        self._ws = {}
         self.film = torch.empty((cfg.timesteps + 1, cfg.n_layers, 2 * cfg.d_model), dtype=dtype, device=self.device)
         check(lib().d3pm_film_table(C.byref(self.shape), C.byref(self.weights.c_struct), _p(self.film), stream_ptr()),
               "d3pm_film_table")
 
-    def workspace(self, batch: int) -> torch.Tensor:
+    def workspace(self, batch: int, slot: int = 0) -> torch.Tensor:
+        """Scratch for one in-flight call; `slot` separates calls that run concurrently on different streams."""
         need = lib().d3pm_workspace_bytes(C.byref(self.shape), batch)
         if need == 0:
             raise D3PMError("d3pm_workspace_bytes: " + lib().d3pm_last_error().decode())
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
     def cond_kv(self, cond_text: torch.Tensor, cond_prompt: torch.Tensor):
         """cond_text [B,S_t,d], cond_prompt [B,S_p,d] -> per-layer K|V tensors [L,B,S,2d]."""
@@ -224,9 +226,9 @@ class Sampler:
                                           _p(post), stream_ptr()), "d3pm_posterior_sample")
         return x_next, post
 
-    def sample_loop(self, x, frame_mask, t_start, t_stop, kv_t, kv_p, seed, utt0=0, flags=0, trace=False):
+    def sample_loop(self, x, frame_mask, t_start, t_stop, kv_t, kv_p, seed, utt0=0, flags=0, trace=False, slot=0):
         cfg, B = self.cfg, x.shape[0]
-        ws = self.workspace(B)
+        ws = self.workspace(B, slot)
         tr = torch.empty((t_start - t_stop, B, cfg.canvas), dtype=torch.int32, device=self.device) if trace else None
         check(lib().d3pm_sample_loop(C.byref(self.shape), C.byref(self.weights.c_struct), B, _p(x), _p(frame_mask),
                                      int(t_start), int(t_stop), _p(self.film), _p(kv_t), _p(kv_p),

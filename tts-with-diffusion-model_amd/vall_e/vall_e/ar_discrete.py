@@ -120,6 +120,8 @@ class AR(nn.Module):
         self.eps = 1.0e-6
         self._sampler = None
         self._sampler_key = None
+        self.loop_streams = 1     # >1: the batch is cut into that many independent chunks on separate HIP streams
+        self._streams = []
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
@@ -200,7 +202,7 @@ class AR(nn.Module):
     @torch.no_grad()
     def generate_audio(self, text_list, proms_list, resps_list=None, *, steps: Optional[int] = None,
                        n_frames: Optional[int] = None, seed: Optional[int] = None, greedy: bool = False,
-                       utt0: int = 0, return_trace: bool = False, flags: int = 0):
+                       utt0: int = 0, return_trace: bool = False, flags: int = 0, streams: Optional[int] = None):
         """Reverse diffusion for len(text_list) utterances.  Positional behaviour as upstream:
         one utterance -> int64 [canvas] (squeezed, untrimmed; rows >= n_frames are sampled from
         final.bias and meaningless).  `resps_list` is ignored, as upstream ignores it (:699)."""
@@ -213,12 +215,33 @@ class AR(nn.Module):
             raise ValueError(f"steps must be in 1..{smp.schedule.timesteps - 1}")
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # follows torch.manual_seed
+        n_streams = max(1, min(B, self.loop_streams if streams is None else streams))
         with torch.cuda.device(self.device):
             cond_text, cond_prompt = self.encode_conditions(text_list, proms_list)
-            kv_t, kv_p = smp.cond_kv(cond_text, cond_prompt)
             x, frame_mask = self.canvas_init(B, n_frames)
             fl = flags | (_hip.FLAG_GREEDY if greedy else 0)
-            trace = smp.sample_loop(x, frame_mask, t_start, 0, kv_t, kv_p, seed, utt0, fl, trace=return_trace)
+            if n_streams == 1 or return_trace:
+                kv_t, kv_p = smp.cond_kv(cond_text, cond_prompt)
+                trace = smp.sample_loop(x, frame_mask, t_start, 0, kv_t, kv_p, seed, utt0, fl, trace=return_trace)
+            else:
+                # utterances are independent: chunks of the batch run the whole loop on their own stream so that
+                # the short kernels of one chunk fill the ramp-up / epilogue bubbles of the others
+                trace = None
+                while len(self._streams) < n_streams:
+                    self._streams.append(torch.cuda.Stream(device=self.device))
+                cur = torch.cuda.current_stream()
+                bounds = [(B * i) // n_streams for i in range(n_streams + 1)]
+                for i in range(n_streams):
+                    lo, hi = bounds[i], bounds[i + 1]
+                    st = self._streams[i]
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        kv_t, kv_p = smp.cond_kv(cond_text[lo:hi], cond_prompt[lo:hi])
+                        smp.sample_loop(x[lo:hi], frame_mask, t_start, 0, kv_t, kv_p, seed, utt0 + lo, fl, slot=i)
+                        for t_ in (kv_t, kv_p, cond_text, cond_prompt, x):
+                            t_.record_stream(st)
+                for i in range(n_streams):
+                    cur.wait_stream(self._streams[i])
         out = x.long()
         out = out[0] if B == 1 else out
         return (out, trace) if return_trace else out
