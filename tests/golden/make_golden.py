@@ -8,6 +8,8 @@ the reference bit for bit at generation time.  Inputs are seed-deterministic (sy
 synth.make_inputs, oracle/philox.py noise), so the fixtures carry no weight blobs.
 
 Fixtures
+    tables_t200.npz     the same scalars for the 200-step schedule of SURVEY §8d config 4 (reference
+                        subclass with timesteps pinned to 200)
     tables_t100.npz     betas + the (d, c, dbar, cbar) scalars read out of the reference's dense
                         [100,1025,1025] tables, with a flag that every table has the closed-form
                         structure d*I + c*1e_M^T, row M = e_M
@@ -139,6 +141,40 @@ def gen_tables(out):
     np.savez(os.path.join(out, "tables_t100.npz"), betas=bits16(m.betas), d=d, c=c, dbar=db, cbar=cb,
              structured=np.array(structured), eps16=bits16(torch.tensor([1e-6], dtype=torch.float16)))
     return m
+
+
+def gen_tables_t200(out):
+    """SURVEY §8d config 4 runs a 200-step schedule.  The reference hard-codes `self.timesteps = 100`
+    (ar_discrete.py:207); a subclass whose `timesteps` is a read-only property makes its own __init__ build
+    the 200-step betas / one-step / cumulative tables with its own statements."""
+    _, ard = rh.load_reference_modules()
+
+    class AR200(ard.AR):
+        timesteps = property(lambda self: 200, lambda self, v: None)
+
+    with rh.cuda_strings_as_cpu():
+        m = AR200(512, 100, 1024, 8, 8, 6)
+    K, M, T = 1025, 512, 200
+    d = np.zeros(T, np.uint16); c = d.copy(); db = d.copy(); cb = d.copy()
+    structured = True
+    for t in range(T):
+        for tab, dd, cc in ((m.q_onestep_mats[t], d, c), (m.q_mats[t], db, cb)):
+            dd[t] = bits16(tab[0, 0:1])[0]
+            cc[t] = bits16(tab[0, M:M + 1])[0]
+            structured &= bool((tab[M] == torch.nn.functional.one_hot(torch.tensor(M), K).half()).all())
+            structured &= bool((tab.diagonal()[:M] == tab[0, 0]).all()) and bool((tab[:M, M] == tab[0, M]).all())
+            off = tab.clone()
+            off.fill_diagonal_(0)
+            off[:, M] = 0
+            structured &= bool((off == 0).all())
+    ob = O.cosine_betas(T)
+    assert torch.equal(ob, m.betas)
+    for mine, ref in zip(O.scalar_tables(ob, T), (d, c, db, cb)):
+        assert np.array_equal(mine.view(np.uint16), ref), "closed-form scalars differ from the 200-step reference tables"
+    assert structured
+    np.savez(os.path.join(out, "tables_t200.npz"), betas=bits16(m.betas), d=d, c=c, dbar=db, cbar=cb,
+             structured=np.array(structured))
+    del m
 
 
 def gen_native(out, m):
@@ -313,6 +349,7 @@ def main():
     torch.manual_seed(0)
     out = HERE
     print("tables ..."); m = gen_tables(out)
+    print("tables (200 steps) ..."); gen_tables_t200(out)
     print("native ..."); gen_native(out, m)
     print("wide ...");   gen_wide(out, m)
     with open(os.path.join(out, "FINGERPRINT.txt"), "w") as f:

@@ -323,3 +323,37 @@ def test_wide_model_logits(wide, tag, dtype, force_generic):
     if dtype == torch.float16:
         nxt, _ = smp.posterior_sample(lg, x, int(g["t"]), seed=123)
         REPORT[key + "_sample_agreement"] = float((nxt[0].cpu().numpy() == g["x_next_seed123"]).mean())
+
+
+# ---- BASELINE.json configs[1] at full size: size-independent properties -----------------------------------
+def test_full_size_libritts_properties():
+    """32 utterances, d=512/H=8/L=6, 768-frame canvas, bf16 (the bench workload), 3 reverse steps:
+    determinism, batch-split invariance (B=32 run == B=5 run on the same global utterance indices),
+    stream-chunk invariance, id range, masked-frame independence -- no oracle needed at this size."""
+    from vall_e.vall_e import synth
+    cfg = synth.D3PMConfig.libritts()
+    sd32 = synth.make_state_dict(cfg, 0)
+    m = make_model(cfg, sd32, torch.bfloat16)
+    texts, proms = synth.make_inputs(cfg, 32, 1)
+    a = m.generate_audio(texts, proms, steps=3, seed=9).cpu()
+    assert a.shape == (32, cfg.canvas) and a.dtype == torch.int64
+    assert int(a.min()) >= 0 and int(a.max()) <= 1024
+    assert torch.equal(a, m.generate_audio(texts, proms, steps=3, seed=9).cpu())
+    assert torch.equal(a[3:8], m.generate_audio(texts[3:8], proms[3:8], steps=3, seed=9, utt0=3).cpu())
+    assert torch.equal(a, m.generate_audio(texts, proms, steps=3, seed=9, streams=4).cpu())
+    assert not torch.equal(a, m.generate_audio(texts, proms, steps=3, seed=10).cpu())
+    # logits never depend on the ids parked in masked-out frames
+    smp = m.sampler()
+    ct, cp = m.encode_conditions(texts[:2], proms[:2])
+    kv_t, kv_p = smp.cond_kv(ct, cp)
+    x, fm = m.canvas_init(2)
+    la, _ = smp.denoise(x, fm, 50, kv_t, kv_p)
+    x[:, cfg.n_frames:] = 77
+    lb, _ = smp.denoise(x, fm, 50, kv_t, kv_p)
+    assert torch.equal(la, lb)
+    # MFMA family vs generic family on the same inputs (different accumulation order / flash softmax only)
+    from vall_e.vall_e import _hip
+    lg, _ = smp.denoise(x, fm, 50, kv_t, kv_p, flags=_hip.FLAG_FORCE_GENERIC)
+    err = (la.float() - lg.float()).abs().max().item()
+    REPORT["libritts_bf16_mfma_vs_generic_logits_max_abs_err"] = err
+    assert err < 0.15

@@ -42,10 +42,14 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert built_lib.d3pm_abi_version() == 1
 
 
-def test_schedule_build_matches_reference_tables(built_lib):
+@pytest.mark.parametrize("timesteps", [100, 200])
+def test_schedule_build_matches_reference_tables(built_lib, timesteps):
+    """d3pm_schedule_build (host C) against the scalars read out of the reference's own dense tables;
+    200 steps = SURVEY §8d config 4 (reference subclass with timesteps pinned, see make_golden.py)."""
     from vall_e.vall_e import _hip
-    s = _hip.Schedule(100)
-    g = load("tables_t100.npz")
+    s = _hip.Schedule(timesteps)
+    g = load(f"tables_t{timesteps}.npz")
+    assert bool(g["structured"])
     for name in ("betas", "d", "c", "dbar", "cbar"):
         assert np.array_equal(getattr(s, name), g[name]), name
 

@@ -448,6 +448,92 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_mfma_big(const T* _
   epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+
+// ---- variant 6: 256 x 256 tile, 16 waves, two LDS stages, asm DMA prefetch (1 workgroup per CU) ----------
+// Half the L2 -> LDS bytes per flop of the 128 x 128 tile; the next K-tile's DMA (4 x 1 KiB per wave) is in
+// flight under the current tile's MFMAs (counted vmcnt + raw barriers as in variant 3).
+template <typename T, int EPI, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_mfma_big_pf(
+    const T* __restrict__ X, int ldx, const T* __restrict__ W, const T* __restrict__ bias, T* Y, int ldy, const T* R1,
+    const T* R2, int ldr, const uint8_t* __restrict__ row_mask, int mask_period, int M, int N, int K, int n_tiles) {
+  constexpr int TBM = 64 * WGM, TBN = 64 * WGN, NW = WGM * WGN;
+  constexpr int A_BYTES = TBM * ROW_BYTES, STAGE = (TBM + TBN) * ROW_BYTES;
+  constexpr int A_INSTR = TBM / 8, B_INSTR = TBN / 8, PER_WAVE = (A_INSTR + B_INSTR) / NW;
+  static_assert((A_INSTR + B_INSTR) % NW == 0, "staging instructions must divide evenly over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+
+  const T* gsrc[PER_WAVE];
+  uint32_t ldst[PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int j = wave * PER_WAVE + i;
+    const bool isA = j < A_INSTR;
+    const int row = (isA ? j : j - A_INSTR) * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    if (isA) {
+      int mr = m0 + row;
+      mr = mr < M ? mr : M - 1;
+      gsrc[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
+    } else {
+      int nr = n0 + row;
+      nr = nr < N ? nr : N - 1;
+      gsrc[i] = W + static_cast<size_t>(nr) * K + logical * 8;
+    }
+    ldst[i] = lds_base + (isA ? 0 : A_BYTES) + (isA ? j : j - A_INSTR) * 1024;
+  }
+  auto issue = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) glds16_asm(gsrc[i] + kt * BK, ldst[i] + buf * STAGE);
+  };
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  const int nk = K / BK;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* bufA = smem + (kt & 1) * STAGE;
+    const char* bufB = bufA + A_BYTES;
+    if (kt + 1 < nk) {
+      issue(kt + 1, (kt + 1) & 1);
+      if (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 fx[4], fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
+        fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 64 + t * 16 + frow, ks * 4 + fch));
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -473,11 +559,12 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   const int variant = g_gemm_variant;
-  const int tbm = variant >= 4 ? 256 : BM, tbn = variant == 5 ? 256 : BN;
+  const int tbm = variant >= 4 ? 256 : BM, tbn = variant >= 5 ? 256 : BN;
   const int n_tiles = (a.N + tbn - 1) / tbn, m_tiles = (a.M + tbm - 1) / tbm;
-  const size_t lds = variant >= 4 ? static_cast<size_t>(tbm + tbn) * ROW_BYTES
+  const size_t lds = variant == 6 ? 2 * static_cast<size_t>(tbm + tbn) * ROW_BYTES
+                     : variant >= 4 ? static_cast<size_t>(tbm + tbn) * ROW_BYTES
                                   : (variant == 2 ? 2 : 4) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
-  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(variant == 5 ? 1024 : (variant == 4 ? 512 : 256));
+  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(variant >= 5 ? 1024 : (variant == 4 ? 512 : 256));
   const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
 
 #define D3PM_GEMM(...)                                                                                          \
@@ -485,7 +572,7 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
       D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),                           \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES));          \
       attr_set = true;                                                                                          \
     }                                                                                                           \
     __VA_ARGS__<<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),        \
@@ -496,7 +583,8 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   } while (0)
 #define D3PM_GEMM_EPI(E)                                                        \
   do {                                                                          \
-    if (variant == 5) D3PM_GEMM(gemm_mfma_big<U, E, 4, 4, 4>);                  \
+    if (variant == 6) D3PM_GEMM(gemm_mfma_big_pf<U, E, 4, 4>);                  \
+    else if (variant == 5) D3PM_GEMM(gemm_mfma_big<U, E, 4, 4, 4>);             \
     else if (variant == 4) D3PM_GEMM(gemm_mfma_big<U, E, 4, 2, 4>);             \
     else if (variant == 3) D3PM_GEMM(gemm_mfma_128_pf<U, E>);                   \
     else if (variant == 2) D3PM_GEMM(gemm_mfma_128_glds<U, E, 1>);              \
