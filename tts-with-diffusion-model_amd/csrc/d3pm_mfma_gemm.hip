@@ -534,6 +534,90 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_mfma_big
   epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+
+// ---- variant 7: 128 x 128 tile, K-step 32, two 16-KiB LDS stages, asm DMA prefetch, 4 workgroups per CU ------
+// PMC on variant 2 (qkv shape): 42 % of the wave cycles wait on the DMA + barrier, 43 % are MFMA issue stalls,
+// MFMA pipe 26 % busy -- the four co-resident workgroups drift into the same phase.  Here every wave keeps
+// its own next K-step in flight under its MFMAs AND four workgroups share the CU.
+// LDS rows are 64 B (32 k): chunk c of row r lives at c ^ (((r >> 3) & 1) * 3) -- conflict-free ds_read_b128.
+__device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) * 3)) << 4); }
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 4) void gemm_mfma_128_k32(const T* __restrict__ X, int ldx, const T* __restrict__ W,
+                                                            const T* __restrict__ bias, T* Y, int ldy, const T* R1,
+                                                            const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
+                                                            int mask_period, int M, int N, int K, int n_tiles) {
+  constexpr int STAGE = 2 * BM * 64;   // A tile 8 KiB | B tile 8 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+
+  const T* gsrc[4];
+  uint32_t ldst[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = wave * 4 + i;                    // 16 wave-instructions of 16 rows: 0..7 from X, 8..15 from W
+    const bool isA = j < 8;
+    const int row = (j & 7) * 16 + (lane >> 2);
+    const int logical = (lane & 3) ^ (((row >> 3) & 1) * 3);
+    if (isA) {
+      int mr = m0 + row;
+      mr = mr < M ? mr : M - 1;
+      gsrc[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
+    } else {
+      int nr = n0 + row;
+      nr = nr < N ? nr : N - 1;
+      gsrc[i] = W + static_cast<size_t>(nr) * K + logical * 8;
+    }
+    ldst[i] = lds_base + (isA ? 0 : BM * 64) + (j & 7) * 1024;
+  }
+  auto issue = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16_asm(gsrc[i] + kt * 32, ldst[i] + buf * STAGE);
+  };
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  const int nk = K / 32;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* bufA = smem + (kt & 1) * STAGE;
+    const char* bufB = bufA + BM * 64;
+    if (kt + 1 < nk) {
+      issue(kt + 1, (kt + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 fx[4], fw[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off32(wm * 64 + t * 16 + frow, fch));
+      fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off32(wn * 64 + t * 16 + frow, fch));
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -559,12 +643,13 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   const int variant = g_gemm_variant;
-  const int tbm = variant >= 4 ? 256 : BM, tbn = variant >= 5 ? 256 : BN;
+  const int tbm = (variant >= 4 && variant <= 6) ? 256 : BM, tbn = (variant == 5 || variant == 6) ? 256 : BN;
   const int n_tiles = (a.N + tbn - 1) / tbn, m_tiles = (a.M + tbm - 1) / tbm;
-  const size_t lds = variant == 6 ? 2 * static_cast<size_t>(tbm + tbn) * ROW_BYTES
+  const size_t lds = variant == 7 ? 2 * TILE_BYTES
+                     : variant == 6 ? 2 * static_cast<size_t>(tbm + tbn) * ROW_BYTES
                      : variant >= 4 ? static_cast<size_t>(tbm + tbn) * ROW_BYTES
                                   : (variant == 2 ? 2 : 4) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
-  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(variant >= 5 ? 1024 : (variant == 4 ? 512 : 256));
+  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block((variant == 5 || variant == 6) ? 1024 : (variant == 4 ? 512 : 256));
   const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
 
 #define D3PM_GEMM(...)                                                                                          \
@@ -583,7 +668,8 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   } while (0)
 #define D3PM_GEMM_EPI(E)                                                        \
   do {                                                                          \
-    if (variant == 6) D3PM_GEMM(gemm_mfma_big_pf<U, E, 4, 4>);                  \
+    if (variant == 7) D3PM_GEMM(gemm_mfma_128_k32<U, E>);                       \
+    else if (variant == 6) D3PM_GEMM(gemm_mfma_big_pf<U, E, 4, 4>);             \
     else if (variant == 5) D3PM_GEMM(gemm_mfma_big<U, E, 4, 4, 4>);             \
     else if (variant == 4) D3PM_GEMM(gemm_mfma_big<U, E, 4, 2, 4>);             \
     else if (variant == 3) D3PM_GEMM(gemm_mfma_128_pf<U, E>);                   \
