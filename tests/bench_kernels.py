@@ -52,6 +52,23 @@ def main():
             line += f" | v{variant}: {t * 1e6:7.1f} us {2 * M * N * K / t / 1e12:7.1f} TF/s"
         print(line, flush=True)
     _hip.set_gemm_variant(2)
+    if "--small" in sys.argv or not quick:
+        Ms = 768
+        print(f"# GEMM  M={Ms} (one utterance: latency regime)")
+        for name, N, K, act, res in shapes:
+            x = torch.randn(Ms, K, device=DEV).to(dtype)
+            w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(dtype)
+            b = torch.randn(N, device=DEV).to(dtype)
+            ldy = (N + 7) // 8 * 8
+            y = torch.empty(Ms, ldy, device=DEV, dtype=dtype)
+            r = torch.randn(Ms, ldy, device=DEV).to(dtype) if res else None
+            line = f"{name:10s} N={N:5d} K={K:5d}"
+            for variant in (2, 3, 7, 1):
+                _hip.set_gemm_variant(variant)
+                t = timeit(lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=ldy), 50)
+                line += f" | v{variant}: {t * 1e6:6.1f} us"
+            print(line, flush=True)
+        _hip.set_gemm_variant(2)
     print("# attention  B=32 H=8 hd=64")
     for name, Tq, S in (("self", 768, 768), ("text", 768, 50), ("prompt", 768, 225)):
         q = torch.randn(32, Tq, 512, device=DEV).to(dtype)
