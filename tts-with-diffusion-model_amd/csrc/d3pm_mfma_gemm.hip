@@ -618,6 +618,102 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128_k32(const T* __restrict_
   epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+
+// ---- variant 8: latency GEMM for one or two utterances (M <= 1536): 16 waves, K split 4 ways INSIDE the workgroup --
+// At M = 768 a 128 x 128 grid has 24-96 workgroups on 256 CUs and every kernel is a serial chain of K/64
+// DMA -> barrier -> MFMA steps (~0.75 us each).  Here four 4-wave groups of one workgroup each own a quarter of K
+// (own 32-KiB LDS tiles, so four times the DMA bytes are in flight per CU and the chain is four times shorter) and
+// the partial accumulators are folded through LDS in a fixed order ((s0+s2)+(s1+s3)) before the usual epilogue.
+template <typename T, int EPI>
+__global__ __launch_bounds__(1024, 4) void gemm_mfma_128_ksplit(const T* __restrict__ X, int ldx, const T* __restrict__ W,
+                                                                const T* __restrict__ bias, T* Y, int ldy, const T* R1,
+                                                                const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
+                                                                int mask_period, int M, int N, int K, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slices x (A tile | B tile) = 128 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: slice branches below are s_cbranch
+  const int slice = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  char* my = smem + slice * 2 * TILE_BYTES;
+
+  const T* gx[4];
+  const T* gw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (w4 * 4 + i) * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    int mr = m0 + row, nr = n0 + row;
+    mr = mr < M ? mr : M - 1;
+    nr = nr < N ? nr : N - 1;
+    gx[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
+    gw[i] = W + static_cast<size_t>(nr) * K + logical * 8;
+  }
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  const int steps = K / BK / 4, k_first = slice * steps;
+  const char* bufA = my;
+  const char* bufB = my + TILE_BYTES;
+  for (int kt = 0; kt < steps; ++kt) {
+    char* base = my + (w4 * 4) * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void)(gx[i] + (k_first + kt) * BK), (lds_void)(base + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void)(gw[i] + (k_first + kt) * BK), (lds_void)(base + TILE_BYTES + i * 1024), 16, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 fx[4], fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
+        fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 64 + t * 16 + frow, ks * 4 + fch));
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
+    }
+    __syncthreads();
+  }
+  // fold the four partial tiles: regions of 16 KiB = one wave's 16 x float4 per lane
+#define D3PM_REGION(idx) (reinterpret_cast<floatx4*>(smem + (idx) * 16384) + lane)
+#define D3PM_SPILL(r)                                                                       \
+  do {                                                                                      \
+    floatx4* r_ = (r);                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) r_[i * 64] = acc[i >> 2][i & 3];         \
+  } while (0)
+#define D3PM_FOLD(r)                                                                        \
+  do {                                                                                      \
+    const floatx4* r_ = (r);                                                                \
+    _Pragma("unroll") for (int i = 0; i < 16; i += 4) {                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[(i + j) >> 2][(i + j) & 3] += r_[(i + j) * 64]; \
+      __builtin_amdgcn_sched_barrier(0);                                                    \
+    }                                                                                       \
+  } while (0)
+  if (slice >= 2) D3PM_SPILL(D3PM_REGION((slice - 2) * 4 + w4));
+  __syncthreads();
+  if (slice < 2) D3PM_FOLD(D3PM_REGION(slice * 4 + w4));
+  __syncthreads();
+  if (slice == 1) D3PM_SPILL(D3PM_REGION(w4));
+  __syncthreads();
+  if (slice == 0) {
+    D3PM_FOLD(D3PM_REGION(w4));
+    epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+  }
+#undef D3PM_REGION
+#undef D3PM_SPILL
+#undef D3PM_FOLD
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -638,18 +734,24 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
+static bool g_latency_gemm = true;
+void set_latency_gemm(int on) { g_latency_gemm = on != 0; }
 static int g_gemm_variant = 2;   // 0 register staging, 1 direct-to-LDS 2 buffers, 2 direct-to-LDS 1 buffer (4 WG/CU), 3 asm DMA prefetch
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
-  const int variant = g_gemm_variant;
+  // one or two utterances: latency regime -> K split inside the workgroup (variant 8).  The rule looks at M
+  // only, so that every batch of >= 3 utterances takes the same kernels (bitwise batch / rank invariance).
+  const bool latency = g_latency_gemm && a.M <= 1536 && a.K % (4 * BK) == 0 && g_gemm_variant == 2;
+  const int variant = latency ? 8 : g_gemm_variant;
   const int tbm = (variant >= 4 && variant <= 6) ? 256 : BM, tbn = (variant == 5 || variant == 6) ? 256 : BN;
   const int n_tiles = (a.N + tbn - 1) / tbn, m_tiles = (a.M + tbm - 1) / tbm;
-  const size_t lds = variant == 7 ? 2 * TILE_BYTES
+  const size_t lds = variant == 8 ? 8 * TILE_BYTES
+                     : variant == 7 ? 2 * TILE_BYTES
                      : variant == 6 ? 2 * static_cast<size_t>(tbm + tbn) * ROW_BYTES
                      : variant >= 4 ? static_cast<size_t>(tbm + tbn) * ROW_BYTES
                                   : (variant == 2 ? 2 : 4) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
-  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block((variant == 5 || variant == 6) ? 1024 : (variant == 4 ? 512 : 256));
+  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block((variant == 5 || variant == 6 || variant == 8) ? 1024 : (variant == 4 ? 512 : 256));
   const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
 
 #define D3PM_GEMM(...)                                                                                          \
@@ -668,7 +770,8 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   } while (0)
 #define D3PM_GEMM_EPI(E)                                                        \
   do {                                                                          \
-    if (variant == 7) D3PM_GEMM(gemm_mfma_128_k32<U, E>);                       \
+    if (variant == 8) D3PM_GEMM(gemm_mfma_128_ksplit<U, E>);                    \
+    else if (variant == 7) D3PM_GEMM(gemm_mfma_128_k32<U, E>);                  \
     else if (variant == 6) D3PM_GEMM(gemm_mfma_big_pf<U, E, 4, 4>);             \
     else if (variant == 5) D3PM_GEMM(gemm_mfma_big<U, E, 4, 4, 4>);             \
     else if (variant == 4) D3PM_GEMM(gemm_mfma_big<U, E, 4, 2, 4>);             \
