@@ -186,7 +186,7 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
 enum {
   D3PM_TUNE_GEMM_VARIANT = 0,
   D3PM_TUNE_ATTN_QUERY_GROUPS = 1, /* 16-query groups per wave: 1 (default) or 2 */
-  D3PM_TUNE_LATENCY_GEMM = 2       /* 1 (default): GEMMs with M <= 1536 rows split K four ways inside the workgroup */
+  D3PM_TUNE_LATENCY_GEMM = 2       /* 1: GEMMs with M <= 1536 rows split K four ways inside the workgroup (default 0: measured slower) */
 };
 int d3pm_set_tuning(int knob, int value);
 

@@ -734,7 +734,7 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
-static bool g_latency_gemm = true;
+static bool g_latency_gemm = false;   // measured slower than variant 2 at M = 768 (13-17 us vs 11-13 us): per-kernel fixed cost, not the K chain, dominates
 void set_latency_gemm(int on) { g_latency_gemm = on != 0; }
 static int g_gemm_variant = 2;   // 0 register staging, 1 direct-to-LDS 2 buffers, 2 direct-to-LDS 1 buffer (4 WG/CU), 3 asm DMA prefetch
 void set_gemm_variant(int v) { g_gemm_variant = v; }
