@@ -117,6 +117,44 @@ int d3pm_film_table(const d3pm_shape *shape, const d3pm_weights *w, void *film /
 int d3pm_cond_kv(const d3pm_shape *shape, const d3pm_weights *w, int batch, const void *cond_text,
                  const void *cond_prompt, void *kv_text, void *kv_prompt, void *stream);
 
+/* Condition encoders (once per utterance) ------------------------------------------------------
+ * Replaces the statements before the loop of AR.generate_audio (ar_discrete.py:736-746): text_emb / proms_emb
+ * (base.py:244-274) gathers, the sinusoidal position add (:84-92 incl. the position-0 quirk for text), two
+ * post-norm nn.TransformerEncoderLayer (nhead 16, ReLU FFN 2048, LayerNorm eps 1e-5, :216-230) and the
+ * timm Mlp(SiLU) of each of `encodertext` / `encoder2`.  Dropout is identity (inference). */
+typedef struct d3pm_encoder_layer_weights {
+  const void *in_w, *in_b;      /* self_attn.in_proj [3d][d], [3d] */
+  const void *out_w, *out_b;    /* self_attn.out_proj [d][d], [d]  */
+  const void *lin1_w, *lin1_b;  /* linear1 [d_ff][d], [d_ff]       */
+  const void *lin2_w, *lin2_b;  /* linear2 [d][d_ff], [d]          */
+  const void *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+} d3pm_encoder_layer_weights;
+
+typedef struct d3pm_encoder_weights {
+  const d3pm_encoder_layer_weights *layers;   /* HOST array of n_layers entries */
+  int32_t n_layers, n_heads, d_ff, mlp_hidden;
+  const void *fc1_w, *fc1_b;                  /* [mlp_hidden][d], [mlp_hidden]  */
+  const void *fc2_w, *fc2_b;                  /* [d][mlp_hidden], [d]           */
+} d3pm_encoder_weights;
+
+typedef struct d3pm_cond_weights {
+  const void *text_emb;    /* [n_classes][d]            (ar_discrete.py:210) */
+  const void *proms_emb;   /* [n_levels][n_classes][d]  (:211)               */
+  const void *pe_text0;    /* [d]           sinusoid of position 0, model dtype */
+  const void *pe_prompt;   /* [s_prompt][d] sinusoid table, model dtype         */
+  int32_t n_levels;
+  d3pm_encoder_weights text_encoder;     /* encodertext (:216-222) */
+  d3pm_encoder_weights prompt_encoder;   /* encoder2    (:224-230) */
+} d3pm_cond_weights;
+
+size_t d3pm_cond_workspace_bytes(const d3pm_shape *shape, const d3pm_cond_weights *cw, int batch);
+
+/* text device int32 [batch][s_text] (zero padded), prompt device int32 [batch][s_prompt][n_levels];
+ * cond_text [batch][s_text][d], cond_prompt [batch][s_prompt][d] of `dtype` (feed d3pm_cond_kv). */
+int d3pm_encode_conditions(const d3pm_shape *shape, const d3pm_cond_weights *cw, int batch, const int32_t *text,
+                           const int32_t *prompt, void *cond_text, void *cond_prompt, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* One denoiser evaluation --------------------------------------------------------------------
  * Replaces the loop body at ar_discrete.py:752-776: resps_emb gather, n_layers x DiTBlock.forward
  * (:126-161, incl. torch's multi_head_attention_forward need_weights branch and timm Mlp), final

@@ -240,11 +240,26 @@ def test_plumbing_config_10_steps(n16):
     assert agree > 0.99
 
 
-def test_conditions_from_torch_rocm_match_oracle(n16, n32):
-    for n, tol in ((n32, 2e-4), (n16, 2e-2)):
-        ct, cp = n.model.encode_conditions([n.texts[0]], [n.proms[0]])
-        assert (ct[0].cpu().float() - n.ct.float()).abs().max().item() < tol
-        assert (cp[0].cpu().float() - n.cp.float()).abs().max().item() < tol
+def test_condition_encoders_match_reference(n16, n32):
+    """HIP condition encoders (d3pm_encode_conditions: embeddings + PE, 2 post-norm encoder layers, SiLU Mlp)
+    against the reference's conditions (golden, via the oracle) -- and the torch-ROCm module path for comparison."""
+    g = load("native_step.npz")
+    for n, tag, tol in ((n32, "f32", 2e-4), (n16, "f16", 1.2e-2)):
+        conv = (lambda a: torch.from_numpy(a)) if tag == "f32" else f16
+        ref_t, ref_p = conv(g[f"cond_text_{tag}"]).float(), conv(g[f"cond_prompt_{tag}"]).float()
+        for name, fn in (("hip", n.model.encode_conditions), ("torch", n.model.encode_conditions_torch)):
+            ct, cp = fn(n.texts[:2], n.proms[:2])
+            et = (ct[0].cpu().float() - ref_t).abs().max().item()
+            ep = (cp[0].cpu().float() - ref_p).abs().max().item()
+            REPORT[f"cond_{name}_{tag}_text_max_abs_err"] = et
+            REPORT[f"cond_{name}_{tag}_prompt_max_abs_err"] = ep
+            assert et < tol and ep < tol, (name, tag, et, ep)
+    # a prompt with fewer quantizer levels: the absent levels contribute nothing (zero one-hot rows upstream)
+    short = [p[:, :3] for p in n32.proms[:1]]
+    with torch.no_grad():
+        cp_ref, _ = n32.orc.conditions(n32.texts[0], short[0])
+    _, cp = n32.model.encode_conditions(n32.texts[:1], short)
+    assert (cp[0].cpu() - cp_ref).abs().max().item() < 2e-4
 
 
 def test_batch_is_independent_runs(n16):
@@ -306,6 +321,12 @@ def test_wide_model_logits(wide, tag, dtype, force_generic):
     assert (cp[:16].float() - conv(g[f"cond_prompt_rows_{tag}"]).float()).abs().max() < 2e-2
     m = make_model(cfg, sd32, dtype)
     smp = m.sampler()
+    ct_hip, cp_hip = m.encode_conditions(texts, proms)              # HIP condition encoders at d=512 (16 heads of 32)
+    ctol = 1e-3 if dtype == torch.float32 else 3e-2
+    ec = (cp_hip[0, :16].cpu().float() - conv(g[f"cond_prompt_rows_{tag}"]).float()).abs().max().item()
+    et = (ct_hip[0, :16].cpu().float() - conv(g[f"cond_text_rows_{tag}"]).float()).abs().max().item()
+    REPORT[f"wide_{tag}_cond_hip_max_abs_err"] = max(ec, et)
+    assert ec < ctol and et < ctol
     kv_t, kv_p = smp.cond_kv(ct[None].to(DEV), cp[None].to(DEV))
     x = torch.from_numpy(g["x_t"].astype(np.int32))[None].to(DEV)
     fm = torch.zeros(cfg.canvas, dtype=torch.uint8, device=DEV)

@@ -266,6 +266,92 @@ int d3pm_cond_kv(const d3pm_shape* sh, const d3pm_weights* w, int batch, const v
   return D3PM_OK;
 }
 
+// ---- condition encoders ----------------------------------------------------------------------------
+struct CondWs { char *x, *tmp, *qkv, *att, *ff; size_t total; };
+static CondWs carve_cond(const d3pm_shape& sh, const d3pm_cond_weights& cw, int batch, char* base) {
+  const size_t es = dtype_size(sh.dtype), d = sh.d_model;
+  const size_t n = static_cast<size_t>(batch) * (sh.s_prompt > sh.s_text ? sh.s_prompt : sh.s_text);
+  auto wide = [](const d3pm_encoder_weights& e) { return static_cast<size_t>(e.d_ff > e.mlp_hidden ? e.d_ff : e.mlp_hidden); };
+  const size_t ffw = wide(cw.text_encoder) > wide(cw.prompt_encoder) ? wide(cw.text_encoder) : wide(cw.prompt_encoder);
+  CondWs w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+  w.x = take(n * d * es);
+  w.tmp = take(n * d * es);
+  w.qkv = take(n * 3 * d * es);
+  w.att = take(n * d * es);
+  w.ff = take(n * ffw * es);
+  w.total = off;
+  return w;
+}
+
+// x (ws.x, [rows][d]) -> out ([rows][d]); `seq` rows per utterance
+static int run_encoder(const d3pm_shape& sh, const d3pm_encoder_weights& e, int batch, int seq, const CondWs& ws, void* out,
+                       hipStream_t s) {
+  const int dt = sh.dtype, d = sh.d_model, n = batch * seq, hd = d / e.n_heads;
+  const size_t es = dtype_size(dt);
+  for (int l = 0; l < e.n_layers; ++l) {
+    const d3pm_encoder_layer_weights& w = e.layers[l];
+    LinearArgs g;
+    g.X = ws.x; g.ldx = d; g.W = w.in_w; g.bias = w.in_b; g.Y = ws.qkv; g.ldy = 3 * d; g.M = n; g.N = 3 * d; g.K = d;
+    D3PM_TRY(run_linear(dt, g, 0, s));
+    AttnArgs a;
+    a.Q = ws.qkv; a.ldq = 3 * d; a.K = at(ws.qkv, d, es); a.V = at(ws.qkv, 2 * d, es); a.ldkv = 3 * d; a.O = ws.att; a.ldo = d;
+    a.B = batch; a.Tq = seq; a.S = seq; a.H = e.n_heads; a.hd = hd; a.scale = static_cast<float>(std::sqrt(1.0 / hd));
+    D3PM_TRY(run_attention(dt, a, 0, s));
+    g = LinearArgs();   // x + self_attn(x), then post-norm
+    g.X = ws.att; g.ldx = d; g.W = w.out_w; g.bias = w.out_b; g.Y = ws.tmp; g.ldy = d; g.R1 = ws.x; g.ldr = d; g.M = n; g.N = d; g.K = d;
+    D3PM_TRY(run_linear(dt, g, 0, s));
+    LayerNormArgs ln;
+    ln.X = ws.tmp; ln.Y = ws.x; ln.w = w.norm1_w; ln.b = w.norm1_b; ln.M = n; ln.d = d; ln.eps = 1e-5f;
+    D3PM_TRY(run_layernorm(dt, ln, 0, s));
+    g = LinearArgs();   // FFN: linear2(relu(linear1(x)))
+    g.X = ws.x; g.ldx = d; g.W = w.lin1_w; g.bias = w.lin1_b; g.Y = ws.ff; g.ldy = e.d_ff; g.M = n; g.N = e.d_ff; g.K = d; g.act = ACT_RELU;
+    D3PM_TRY(run_linear(dt, g, 0, s));
+    g = LinearArgs();
+    g.X = ws.ff; g.ldx = e.d_ff; g.W = w.lin2_w; g.bias = w.lin2_b; g.Y = ws.tmp; g.ldy = d; g.R1 = ws.x; g.ldr = d; g.M = n; g.N = d; g.K = e.d_ff;
+    D3PM_TRY(run_linear(dt, g, 0, s));
+    ln = LayerNormArgs();
+    ln.X = ws.tmp; ln.Y = ws.x; ln.w = w.norm2_w; ln.b = w.norm2_b; ln.M = n; ln.d = d; ln.eps = 1e-5f;
+    D3PM_TRY(run_layernorm(dt, ln, 0, s));
+  }
+  LinearArgs g;   // timm Mlp: fc2(silu(fc1(x)))
+  g.X = ws.x; g.ldx = d; g.W = e.fc1_w; g.bias = e.fc1_b; g.Y = ws.ff; g.ldy = e.mlp_hidden; g.M = n; g.N = e.mlp_hidden; g.K = d; g.act = ACT_SILU;
+  D3PM_TRY(run_linear(dt, g, 0, s));
+  g = LinearArgs();
+  g.X = ws.ff; g.ldx = e.mlp_hidden; g.W = e.fc2_w; g.bias = e.fc2_b; g.Y = out; g.ldy = d; g.M = n; g.N = d; g.K = e.mlp_hidden;
+  return run_linear(dt, g, 0, s);
+}
+
+static bool encoder_ok(const d3pm_encoder_weights& e, int d) {
+  return e.layers && e.n_layers > 0 && e.n_heads > 0 && d % e.n_heads == 0 && e.d_ff > 0 && e.mlp_hidden > 0 && e.fc1_w &&
+         e.fc1_b && e.fc2_w && e.fc2_b;
+}
+
+size_t d3pm_cond_workspace_bytes(const d3pm_shape* sh, const d3pm_cond_weights* cw, int batch) {
+  if (check_shape(sh, batch) != D3PM_OK || !cw) return 0;
+  return carve_cond(*sh, *cw, batch, nullptr).total;
+}
+
+int d3pm_encode_conditions(const d3pm_shape* sh, const d3pm_cond_weights* cw, int batch, const int32_t* text,
+                           const int32_t* prompt, void* cond_text, void* cond_prompt, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  D3PM_TRY(check_shape(sh, batch));
+  D3PM_REQUIRE(cw && text && prompt && cond_text && cond_prompt && workspace && cw->text_emb && cw->proms_emb &&
+                   cw->pe_text0 && cw->pe_prompt && cw->n_levels > 0,
+               D3PM_E_ARG, "d3pm_encode_conditions: null pointer");
+  D3PM_REQUIRE(encoder_ok(cw->text_encoder, sh->d_model) && encoder_ok(cw->prompt_encoder, sh->d_model), D3PM_E_ARG,
+               "d3pm_encode_conditions: incomplete encoder weights");
+  CondWs ws = carve_cond(*sh, *cw, batch, static_cast<char*>(workspace));
+  D3PM_REQUIRE(workspace_bytes >= ws.total, D3PM_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  D3PM_TRY(cond_embed_text(sh->dtype, text, cw->text_emb, cw->pe_text0, ws.x, batch * sh->s_text, sh->d_model, sh->n_classes, s));
+  D3PM_TRY(run_encoder(*sh, cw->text_encoder, batch, sh->s_text, ws, cond_text, s));
+  D3PM_TRY(cond_embed_prompt(sh->dtype, prompt, cw->n_levels, cw->proms_emb, cw->pe_prompt, ws.x, batch * sh->s_prompt,
+                             sh->s_prompt, sh->d_model, sh->n_classes, s));
+  return run_encoder(*sh, cw->prompt_encoder, batch, sh->s_prompt, ws, cond_prompt, s);
+}
+
 int d3pm_denoise_step(const d3pm_shape* sh, const d3pm_weights* w, int batch, const int32_t* x_t,
                       const uint8_t* frame_mask, int t, const void* film, const void* kv_text, const void* kv_prompt,
                       void* workspace, size_t workspace_bytes, void* logits_out, void* hidden_out, int only_layers,

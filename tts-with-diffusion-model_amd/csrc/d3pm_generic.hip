@@ -116,6 +116,8 @@ __global__ __launch_bounds__(256) void linear_tiled(const T* __restrict__ X, int
       if (n >= N) continue;
       float v = rn<T>(acc[i][j] + (bias ? ldf(bias + n) : 0.f));
       if (act == ACT_GELU) v = rn<T>(gelu_erf(v));
+      else if (act == ACT_RELU) v = fmaxf(v, 0.f);
+      else if (act == ACT_SILU) v = rn<T>(v / (1.0f + expf(-v)));
       if (R1) {
         float r = ldf(R1 + static_cast<size_t>(m) * ldr + n);
         if (R2) r = rn<T>(r + ldf(R2 + static_cast<size_t>(m) * ldr + n));
@@ -187,6 +189,38 @@ __global__ __launch_bounds__(256) void attention_rows(const T* __restrict__ Q, i
   }
 }
 
+// text condition rows: W[tok] + PE(position 0) (the x.shape[0] quirk, ar_discrete.py:89,741)
+template <typename T>
+__global__ void cond_text_rows(const int32_t* __restrict__ tok, const T* __restrict__ table, const T* __restrict__ pe0,
+                               T* __restrict__ y, int rows, int d, int n_classes) {
+  int row = blockIdx.x;
+  if (row >= rows) return;
+  int id = tok[row];
+  id = id < 0 ? 0 : (id >= n_classes ? n_classes - 1 : id);
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    stf(y + static_cast<size_t>(row) * d + c, ldf(table + static_cast<size_t>(id) * d + c) + ldf(pe0 + c));
+}
+
+// prompt condition rows: sum over quantizer levels (fp32, one rounding: base.py:255-274) + PE(position) (ar_discrete.py:745)
+template <typename T>
+__global__ void cond_prompt_rows(const int32_t* __restrict__ codes, int n_levels, const T* __restrict__ tables,
+                                 const T* __restrict__ pe, T* __restrict__ y, int rows, int s_prompt, int d, int n_classes) {
+  int row = blockIdx.x;
+  if (row >= rows) return;
+  const int32_t* cr = codes + static_cast<size_t>(row) * n_levels;
+  const T* per = pe + static_cast<size_t>(row % s_prompt) * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float acc = 0.f;
+    for (int l = 0; l < n_levels; ++l) {
+      int id = cr[l];
+      if (id < 0) continue;                       // level absent in the prompt: contributes nothing (zero one-hot row)
+      id = id >= n_classes ? n_classes - 1 : id;
+      acc += ldf(tables + (static_cast<size_t>(l) * n_classes + id) * d + c);
+    }
+    stf(y + static_cast<size_t>(row) * d + c, rn<T>(acc) + ldf(per + c));
+  }
+}
+
 template <typename F> int dispatch(int dtype, F&& f) {
   switch (dtype) {
     case D3PM_F32: return f(static_cast<float*>(nullptr));
@@ -205,6 +239,29 @@ int embed_tokens(int dtype, const EmbedArgs& a, hipStream_t s) {
     int threads = a.d >= 256 ? 256 : (a.d >= 128 ? 128 : 64);
     embed_rows<T><<<a.M, threads, 0, s>>>(a.tokens, a.frame_mask, a.canvas, static_cast<const T*>(a.table),
                                           static_cast<T*>(a.Y), a.M, a.d, a.n_classes);
+    D3PM_LAUNCH_CHECK();
+    return D3PM_OK;
+  });
+}
+
+int cond_embed_text(int dtype, const int32_t* tok, const void* table, const void* pe0, void* y, int rows, int d,
+                    int n_classes, hipStream_t s) {
+  return dispatch(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    cond_text_rows<T><<<rows, d >= 256 ? 256 : 64, 0, s>>>(tok, static_cast<const T*>(table), static_cast<const T*>(pe0),
+                                                        static_cast<T*>(y), rows, d, n_classes);
+    D3PM_LAUNCH_CHECK();
+    return D3PM_OK;
+  });
+}
+
+int cond_embed_prompt(int dtype, const int32_t* codes, int n_levels, const void* tables, const void* pe, void* y,
+                      int rows, int s_prompt, int d, int n_classes, hipStream_t s) {
+  return dispatch(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    cond_prompt_rows<T><<<rows, d >= 256 ? 256 : 64, 0, s>>>(codes, n_levels, static_cast<const T*>(tables),
+                                                          static_cast<const T*>(pe), static_cast<T*>(y), rows, s_prompt,
+                                                          d, n_classes);
     D3PM_LAUNCH_CHECK();
     return D3PM_OK;
   });

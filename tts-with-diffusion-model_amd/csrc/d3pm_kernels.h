@@ -8,11 +8,11 @@
 
 namespace d3pm {
 
-enum { ACT_NONE = 0, ACT_GELU = 1 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SILU = 3 };
 
 // Y[M][N] = epilogue(X[M][K] . W[N][K]^T + bias)      (torch.nn.functional.linear layout)
 // epilogue, with rn() = round to the storage dtype exactly where the eager reference rounds:
-//   v = rn(acc + bias); if act: v = rn(gelu_erf(v));
+//   v = rn(acc + bias); if act: v = rn(act(v))   (exact-erf GELU, ReLU or SiLU);
 //   if R1 && R2: v = rn(rn(R1 + R2) + v)  else if R1: v = rn(R1 + v);
 //   if row_mask: v = v * row_mask[row % mask_period]
 struct LinearArgs {
@@ -75,6 +75,11 @@ int generic_linear(int dtype, const LinearArgs& a, hipStream_t s);
 int generic_attention(int dtype, const AttnArgs& a, hipStream_t s);
 int generic_layernorm(int dtype, const LayerNormArgs& a, hipStream_t s);
 int embed_tokens(int dtype, const EmbedArgs& a, hipStream_t s);
+// condition-side embeddings: text rows = rn(W[tok] + pe0); prompt rows = rn(rn(sum_l W[l][tok_l]) + pe[s])
+int cond_embed_text(int dtype, const int32_t* tok, const void* table, const void* pe0, void* y, int rows, int d,
+                    int n_classes, hipStream_t s);
+int cond_embed_prompt(int dtype, const int32_t* codes, int n_levels, const void* tables, const void* pe, void* y,
+                      int rows, int s_prompt, int d, int n_classes, hipStream_t s);
 int posterior_sample(const SampleArgs& a, hipStream_t s);
 
 // MFMA family: return D3PM_E_SHAPE when the shape does not fit (caller falls back to generic)

@@ -56,8 +56,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 // Epilogue on the accumulator layout D[n = nt*16 + (lane>>4)*4 + r][m = mt*16 + (lane&15)]: a lane owns 4
 // consecutive columns of one row per (mt, nt).  Residual loads are branch-free (clamped addresses) and
 // batched per row so that four 8-byte loads are in flight together; only the stores are predicated.
-// EPI bits: 1 = exact-erf GELU, 2 = one residual (R1), 4 = two residuals (R1, R2), 8 = frame mask
-constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8;
+// EPI bits: 1 = exact-erf GELU, 2 = one residual (R1), 4 = two residuals (R1, R2), 8 = frame mask, 16 = ReLU, 32 = SiLU
+constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8, EPI_RELU = 16, EPI_SILU = 32;
 
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[4][4], const T* __restrict__ bias, T* Y, int ldy,
@@ -97,6 +97,8 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[4][4], const T* __
       for (int r = 0; r < 4; ++r) {
         v[r] = rn<T>(acc[nt][mt][r] + bv[nt][r]);
         if (kGelu) v[r] = rn<T>(gelu_erf(v[r]));
+        if (EPI & EPI_RELU) v[r] = fmaxf(v[r], 0.f);
+        if (EPI & EPI_SILU) v[r] = rn<T>(v[r] / (1.0f + expf(-v[r])));
         if (kR1) {
           float res = static_cast<float>(p1[nt].v[r]);
           if (kR2) res = rn<T>(res + static_cast<float>(p2[nt].v[r]));
@@ -726,7 +728,7 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   if (a.R2 && !aligned(a.R2, 8)) return false;
   if (static_cast<long long>(a.M) * a.N < 128 * 128) return false;     // not worth a 128^2 tile
   const bool gelu = a.act == ACT_GELU, r1 = a.R1 != nullptr, r2 = a.R2 != nullptr, mk = a.row_mask != nullptr;
-  if (a.act != ACT_NONE && !gelu) return false;
+  if (a.act == ACT_RELU || a.act == ACT_SILU) return !r1 && !mk;   // condition-encoder FFN epilogues (default variant only)
   if (r2 && !r1) return false;
   // instantiated epilogues: plain, GELU, R1, R1+R2, R1+mask
   if (gelu && (r1 || mk)) return false;
@@ -743,7 +745,8 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   // one or two utterances: latency regime -> K split inside the workgroup (variant 8).  The rule looks at M
   // only, so that every batch of >= 3 utterances takes the same kernels (bitwise batch / rank invariance).
   const bool latency = g_latency_gemm && a.M <= 1536 && a.K % (4 * BK) == 0 && g_gemm_variant == 2;
-  const int variant = latency ? 8 : g_gemm_variant;
+  const bool ffn_act = a.act == ACT_RELU || a.act == ACT_SILU;
+  const int variant = ffn_act ? 2 : (latency ? 8 : g_gemm_variant);
   const int tbm = (variant >= 4 && variant <= 6) ? 256 : BM, tbn = (variant == 5 || variant == 6) ? 256 : BN;
   const int n_tiles = (a.N + tbn - 1) / tbn, m_tiles = (a.M + tbm - 1) / tbm;
   const size_t lds = variant == 8 ? 8 * TILE_BYTES
@@ -752,7 +755,8 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
                      : variant >= 4 ? static_cast<size_t>(tbm + tbn) * ROW_BYTES
                                   : (variant == 2 ? 2 : 4) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
   dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block((variant == 5 || variant == 6 || variant == 8) ? 1024 : (variant == 4 ? 512 : 256));
-  const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
+  const int epi = (a.act == ACT_GELU ? EPI_GELU : a.act == ACT_RELU ? EPI_RELU : a.act == ACT_SILU ? EPI_SILU : 0) |
+                  (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
 
 #define D3PM_GEMM(...)                                                                                          \
   do {                                                                                                          \
@@ -788,6 +792,8 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
       case EPI_R1: D3PM_GEMM_EPI(EPI_R1);
       case EPI_R2: D3PM_GEMM_EPI(EPI_R2);
       case EPI_R1 | EPI_MASK: D3PM_GEMM_EPI(EPI_R1 | EPI_MASK);
+      case EPI_RELU: if (variant == 2) D3PM_GEMM(gemm_mfma_128_glds<U, EPI_RELU, 1>); break;
+      case EPI_SILU: if (variant == 2) D3PM_GEMM(gemm_mfma_128_glds<U, EPI_SILU, 1>); break;
       default: break;
     }
     return D3PM_E_SHAPE;

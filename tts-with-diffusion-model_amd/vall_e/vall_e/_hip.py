@@ -40,6 +40,26 @@ class Weights(C.Structure):
                 ("final_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights))]
 
 
+_ENC_LAYER_FIELDS = ("in_w", "in_b", "out_w", "out_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b", "norm1_w", "norm1_b",
+                     "norm2_w", "norm2_b")
+
+
+class EncoderLayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _ENC_LAYER_FIELDS]
+
+
+class EncoderWeights(C.Structure):
+    _fields_ = [("layers", C.POINTER(EncoderLayerWeights)), ("n_layers", C.c_int32), ("n_heads", C.c_int32),
+                ("d_ff", C.c_int32), ("mlp_hidden", C.c_int32), ("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p),
+                ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p)]
+
+
+class CondWeights(C.Structure):
+    _fields_ = [("text_emb", C.c_void_p), ("proms_emb", C.c_void_p), ("pe_text0", C.c_void_p),
+                ("pe_prompt", C.c_void_p), ("n_levels", C.c_int32), ("text_encoder", EncoderWeights),
+                ("prompt_encoder", EncoderWeights)]
+
+
 class ScheduleC(C.Structure):
     _fields_ = [("timesteps", C.c_int32), ("d", C.POINTER(C.c_uint16)), ("c", C.POINTER(C.c_uint16)),
                 ("dbar", C.POINTER(C.c_uint16)), ("cbar", C.POINTER(C.c_uint16))]
@@ -55,6 +75,9 @@ SIGNATURES = {
     "d3pm_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int]),
     "d3pm_film_table": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_void_p, C.c_void_p]),
     "d3pm_cond_kv": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_int] + [C.c_void_p] * 5),
+    "d3pm_cond_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(CondWeights), C.c_int]),
+    "d3pm_encode_conditions": (C.c_int, [C.POINTER(Shape), C.POINTER(CondWeights), C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "d3pm_denoise_step": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]),
@@ -167,6 +190,38 @@ class DeviceWeights:
                                 ptr("final.bias"), self.blocks)
 
 
+class DeviceCondWeights:
+    """Pointer tables of the two condition encoders (+ embeddings and position tables)."""
+
+    def __init__(self, tensors: dict, cfg, pe_text0: torch.Tensor, pe_prompt: torch.Tensor):
+        self._keep = [pe_text0, pe_prompt]
+
+        def ptr(key):
+            t = tensors[key]
+            if not (t.is_cuda and t.is_contiguous()):
+                raise D3PMError(f"weight {key} must be a contiguous device tensor")
+            self._keep.append(t)
+            return t.data_ptr()
+
+        names = {"in_w": "self_attn.in_proj_weight", "in_b": "self_attn.in_proj_bias", "out_w": "self_attn.out_proj.weight",
+                 "out_b": "self_attn.out_proj.bias", "lin1_w": "linear1.weight", "lin1_b": "linear1.bias",
+                 "lin2_w": "linear2.weight", "lin2_b": "linear2.bias", "norm1_w": "norm1.weight", "norm1_b": "norm1.bias",
+                 "norm2_w": "norm2.weight", "norm2_b": "norm2.bias"}
+
+        def encoder(name, mult):
+            layers = (EncoderLayerWeights * cfg.cond_layers)()
+            for j in range(cfg.cond_layers):
+                for field, key in names.items():
+                    setattr(layers[j], field, ptr(f"{name}.0.layers.{j}.{key}"))
+            self._keep.append(layers)
+            return EncoderWeights(layers, cfg.cond_layers, cfg.cond_heads, cfg.cond_ff, mult * cfg.d_model,
+                                  ptr(f"{name}.1.fc1.weight"), ptr(f"{name}.1.fc1.bias"), ptr(f"{name}.1.fc2.weight"),
+                                  ptr(f"{name}.1.fc2.bias"))
+
+        self.c_struct = CondWeights(ptr("text_emb.weight"), ptr("proms_emb.weight"), pe_text0.data_ptr(),
+                                    pe_prompt.data_ptr(), cfg.n_levels, encoder("encodertext", 2), encoder("encoder2", 3))
+
+
 def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -174,10 +229,13 @@ def _p(t):
 class Sampler:
     """Thin object API over the C entry points for one (shape, weights) pair."""
 
-    def __init__(self, cfg, tensors: dict, dtype: torch.dtype, device):
+    def __init__(self, cfg, tensors: dict, dtype: torch.dtype, device, pe_text0=None, pe_prompt=None):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.shape = make_shape(cfg, dtype)
         self.weights = DeviceWeights(tensors, cfg.n_layers)
+        self.cond_weights = (DeviceCondWeights(tensors, cfg, pe_text0, pe_prompt)
+                             if pe_text0 is not None and "encodertext.1.fc1.weight" in tensors else None)
+        self._cond_ws = None
         self.schedule = Schedule(cfg.timesteps)
         self._ws = {}
         self.film = torch.empty((cfg.timesteps + 1, cfg.n_layers, 2 * cfg.d_model), dtype=dtype, device=self.device)
@@ -193,6 +251,24 @@ class Sampler:
         if ws is None or ws.numel() < need:
             ws = self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return ws
+
+    def encode_conditions(self, text: torch.Tensor, prompt: torch.Tensor):
+        """text int32 [B,S_t] (zero padded), prompt int32 [B,S_p,n_levels] (-1 = level absent) ->
+        (cond_text [B,S_t,d], cond_prompt [B,S_p,d]) through d3pm_encode_conditions."""
+        if self.cond_weights is None:
+            raise D3PMError("this sampler was bound without condition-encoder weights")
+        cfg, B = self.cfg, text.shape[0]
+        assert text.shape == (B, cfg.s_text) and prompt.shape == (B, cfg.s_prompt, cfg.n_levels)
+        text, prompt = text.to(torch.int32).contiguous(), prompt.to(torch.int32).contiguous()
+        need = lib().d3pm_cond_workspace_bytes(C.byref(self.shape), C.byref(self.cond_weights.c_struct), B)
+        if self._cond_ws is None or self._cond_ws.numel() < need:
+            self._cond_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ct = torch.empty((B, cfg.s_text, cfg.d_model), dtype=self.dtype, device=self.device)
+        cp = torch.empty((B, cfg.s_prompt, cfg.d_model), dtype=self.dtype, device=self.device)
+        check(lib().d3pm_encode_conditions(C.byref(self.shape), C.byref(self.cond_weights.c_struct), B, _p(text),
+                                           _p(prompt), _p(ct), _p(cp), _p(self._cond_ws), self._cond_ws.numel(),
+                                           stream_ptr()), "d3pm_encode_conditions")
+        return ct, cp
 
     def cond_kv(self, cond_text: torch.Tensor, cond_prompt: torch.Tensor):
         """cond_text [B,S_t,d], cond_prompt [B,S_p,d] -> per-layer K|V tensors [L,B,S,2d]."""

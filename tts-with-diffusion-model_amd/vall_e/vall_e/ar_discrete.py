@@ -157,11 +157,12 @@ class AR(nn.Module):
             raise RuntimeError("the D3PM sampler runs on MI355X only: move the model to a HIP device "
                                "(model.to('cuda')); there is no CPU path")
         sd = {k: v for k, v in self.named_parameters()}
-        key = (self.dtype, self.device, tuple((k, v.data_ptr(), v._version) for k, v in sd.items()
-                                              if k.startswith(("blocks.", "final.", "resps_emb", "time_emb"))))
+        key = (self.dtype, self.device, tuple((k, v.data_ptr(), v._version) for k, v in sd.items()))
         if self._sampler is None or self._sampler_key != key:
             with torch.cuda.device(self.device):
-                self._sampler = _hip.Sampler(self.cfg, {k: v.detach() for k, v in sd.items()}, self.dtype, self.device)
+                pe_text0, pe_prompt = self._pe()
+                self._sampler = _hip.Sampler(self.cfg, {k: v.detach() for k, v in sd.items()}, self.dtype, self.device,
+                                             pe_text0.contiguous(), pe_prompt.contiguous())
             self._sampler_key = key
         return self._sampler
 
@@ -172,13 +173,26 @@ class AR(nn.Module):
             return x[:n]
         return F.pad(x, [0, 0] * (x.dim() - 1) + [0, n - x.shape[0]])
 
-    def encode_conditions(self, text_list: Sequence[Tensor], proms_list: Sequence[Tensor]):
-        """-> (cond_text [B,S_t,d], cond_prompt [B,S_p,d]).  Same statements as upstream
-        (:711-746): zero pad / truncate, embed, text gets PE(position 0) on every phoneme (the
-        x.shape[0] quirk at :89), the prompt true positions; two post-norm encoder layers + Mlp."""
+    def _padded_inputs(self, text_list, proms_list):
         cfg, dev = self.cfg, self.device
         text = torch.stack([self._pad_rows(t.to(dev).long(), cfg.s_text) for t in text_list])           # [B,S_t]
         prom = torch.stack([self._pad_rows(p.to(dev).long(), cfg.s_prompt) for p in proms_list])        # [B,S_p,l]
+        return text, prom
+
+    def encode_conditions(self, text_list: Sequence[Tensor], proms_list: Sequence[Tensor]):
+        """-> (cond_text [B,S_t,d], cond_prompt [B,S_p,d]) through the HIP condition encoders
+        (d3pm_encode_conditions).  Same statements as upstream (:711-746): zero pad / truncate, embed, text gets
+        PE(position 0) on every phoneme (the x.shape[0] quirk at :89), the prompt true positions; two post-norm
+        encoder layers + Mlp.  Prompts with fewer than n_levels quantizer levels: the missing levels add nothing."""
+        text, prom = self._padded_inputs(text_list, proms_list)
+        if prom.shape[-1] < self.cfg.n_levels:
+            prom = F.pad(prom, (0, self.cfg.n_levels - prom.shape[-1]), value=-1)
+        with torch.cuda.device(self.device):
+            return self.sampler().encode_conditions(text, prom)
+
+    def encode_conditions_torch(self, text_list: Sequence[Tensor], proms_list: Sequence[Tensor]):
+        """The same encoders on PyTorch-ROCm modules (tests cross-check the HIP path against it)."""
+        text, prom = self._padded_inputs(text_list, proms_list)
         pe_text0, pe_prompt = self._pe()
         ct = self.text_emb(text) + pe_text0
         cp = self.proms_emb(prom) + pe_prompt
