@@ -67,9 +67,17 @@ static int run_linear(int dtype, const LinearArgs& a, uint32_t flags, hipStream_
   return generic_linear(dtype, a, s);
 }
 static int run_attention(int dtype, const AttnArgs& a, uint32_t flags, hipStream_t s) {
-  ProfScope p(D3PM_K_ATTN, s, 4.0 * a.B * a.H * a.Tq * static_cast<double>(a.S) * a.hd,
-              dtype_size(dtype) * (2.0 * a.B * a.Tq * a.H * a.hd + 2.0 * a.B * a.S * a.H * a.hd));
+  ProfScope p(D3PM_K_ATTN, s, 4.0 * a.B * a.H * a.Tq * static_cast<double>(a.S + a.S2) * a.hd,
+              dtype_size(dtype) * (2.0 * a.B * a.Tq * a.H * a.hd + 2.0 * a.B * (a.S + a.S2) * a.H * a.hd));
   if (!(flags & D3PM_FLAG_FORCE_GENERIC) && mfma_attention_supported(dtype, a)) return mfma_attention(dtype, a, s);
+  if (a.Q2) {   // the generic kernel takes one problem per launch
+    AttnArgs first = a, second = a;
+    first.Q2 = first.K2 = first.V2 = nullptr; first.O2 = nullptr; first.S2 = 0;
+    second = first;
+    second.Q = a.Q2; second.K = a.K2; second.V = a.V2; second.O = a.O2; second.S = a.S2;
+    int rc = generic_attention(dtype, first, s);
+    return rc != D3PM_OK ? rc : generic_attention(dtype, second, s);
+  }
   return generic_attention(dtype, a, s);
 }
 static int run_layernorm(int dtype, const LayerNormArgs& a, uint32_t flags, hipStream_t s) {
@@ -176,12 +184,13 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
         D3PM_TRY(run_linear(dt, g, flags, s));
       }
     }
-    for (int which = 0; which < 2; ++which) {
-      const int S = which ? sh.s_prompt : sh.s_text;
-      const void* kv = at(which ? kv_prompt : kv_text, static_cast<size_t>(l) * batch * S * 2 * d, es);
+    {   // text and prompt cross-attention are independent: one paired launch
+      const void* kvt = at(kv_text, static_cast<size_t>(l) * batch * sh.s_text * 2 * d, es);
+      const void* kvp = at(kv_prompt, static_cast<size_t>(l) * batch * sh.s_prompt * 2 * d, es);
       a = AttnArgs();
-      a.Q = which ? q_prom : q_text; a.ldq = d; a.K = kv; a.V = at(kv, d, es); a.ldkv = 2 * d;
-      a.O = which ? ws.att2 : ws.att; a.ldo = d; a.B = batch; a.Tq = T; a.S = S; a.H = H; a.hd = hd; a.scale = scale;
+      a.Q = q_text; a.ldq = d; a.K = kvt; a.V = at(kvt, d, es); a.ldkv = 2 * d; a.O = ws.att; a.ldo = d;
+      a.B = batch; a.Tq = T; a.S = sh.s_text; a.H = H; a.hd = hd; a.scale = scale;
+      a.Q2 = q_prom; a.K2 = kvp; a.V2 = at(kvp, d, es); a.O2 = ws.att2; a.S2 = sh.s_prompt;
       D3PM_TRY(run_attention(dt, a, flags, s));
     }
     // o_text -> h (free now); x = (x + o_text) + o_prompt, rounded at each add like the eager sum

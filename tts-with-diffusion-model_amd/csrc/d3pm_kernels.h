@@ -34,6 +34,9 @@ struct AttnArgs {
   void* O = nullptr; int ldo = 0;
   int B = 0, Tq = 0, S = 0, H = 0, hd = 0;
   float scale = 1.f;
+  // optional second, independent problem with the same B / Tq / H / hd launched in the same grid
+  // (the text and prompt cross-attentions of one DiT block): its own Q, K/V (S2 keys) and output
+  const void* Q2 = nullptr; const void* K2 = nullptr; const void* V2 = nullptr; void* O2 = nullptr; int S2 = 0;
 };
 
 // Y = LN(X) * w + b (eps), optionally FiLM: Y = rn(rn(LN * rn(1 + film[c])) + film[d + c])

@@ -57,7 +57,9 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
 template <typename T, int QG>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
 __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
                                                       const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo,
-                                                      int Tq, int S, float scale, int H, int n_qblocks) {
+                                                      int Tq, int S, float scale, int H, int n_qblocks,
+                                                      const T* __restrict__ Q2, const T* __restrict__ K2,
+                                                      const T* __restrict__ V2, T* __restrict__ O2, int S2, int n_first) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE];   // [buffer][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
@@ -67,6 +69,10 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
   {
     const int nblocks = gridDim.x, q = nblocks >> 3, r = nblocks & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  if (bid >= n_first) {   // second problem of a paired launch (block-uniform)
+    bid -= n_first;
+    Q = Q2; Kp = K2; Vp = V2; O = O2; S = S2;
   }
   const int qb = bid % n_qblocks, h = (bid / n_qblocks) % H, b = bid / (n_qblocks * H);
   const int q0 = (qb * 4 + wave) * (16 * QG);
@@ -242,6 +248,7 @@ bool mfma_attention_supported(int dtype, const AttnArgs& a) {
   if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
   if (a.hd != HD || a.S < 1 || a.Tq < 1) return false;
   if (a.ldq % 8 || a.ldkv % 8 || a.ldo % 4) return false;
+  if (a.Q2 && !(a.S2 >= 1 && aligned(a.Q2, 16) && aligned(a.K2, 16) && aligned(a.V2, 16) && aligned(a.O2, 8))) return false;
   return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 8);
 }
 
@@ -251,11 +258,14 @@ void set_attn_qg(int v) { g_attn_qg = v; }
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
   const int qg = g_attn_qg == 1 ? 1 : 2, per_block = 64 * qg;
   const int n_qblocks = (a.Tq + per_block - 1) / per_block;
-  dim3 grid(static_cast<unsigned>(n_qblocks) * a.H * a.B), block(256);
+  const int n_first = n_qblocks * a.H * a.B;
+  dim3 grid(static_cast<unsigned>(n_first) * (a.Q2 ? 2 : 1)), block(256);
 #define D3PM_ATTN(T, QG)                                                                                             \
   attn_mfma_hd64<T, QG><<<grid, block, 0, s>>>(static_cast<const T*>(a.Q), a.ldq, static_cast<const T*>(a.K),        \
                                                static_cast<const T*>(a.V), a.ldkv, static_cast<T*>(a.O), a.ldo, a.Tq, \
-                                               a.S, a.scale, a.H, n_qblocks)
+                                               a.S, a.scale, a.H, n_qblocks, static_cast<const T*>(a.Q2),                 \
+                                               static_cast<const T*>(a.K2), static_cast<const T*>(a.V2),                 \
+                                               static_cast<T*>(a.O2), a.S2, n_first)
   if (dtype == D3PM_F16) { if (qg == 1) D3PM_ATTN(f16, 1); else D3PM_ATTN(f16, 2); }
   else { if (qg == 1) D3PM_ATTN(bf16, 1); else D3PM_ATTN(bf16, 2); }
 #undef D3PM_ATTN
