@@ -33,7 +33,7 @@ def gelu32(v):
     return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 7], ids=lambda v: f"gemm_v{v}")
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 7, 9], ids=lambda v: f"gemm_v{v}")
 def gemm_variant(request, built_lib):
     """Every staging variant of the MFMA GEMM must pass the same numerics (the default is restored afterwards)."""
     from vall_e.vall_e import _hip

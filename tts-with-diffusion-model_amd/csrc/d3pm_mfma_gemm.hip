@@ -59,15 +59,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 // EPI bits: 1 = exact-erf GELU, 2 = one residual (R1), 4 = two residuals (R1, R2), 8 = frame mask, 16 = ReLU, 32 = SiLU
 constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8, EPI_RELU = 16, EPI_SILU = 32;
 
-template <typename T, int EPI>
-__device__ __forceinline__ void epilogue_store(floatx4 (&acc)[4][4], const T* __restrict__ bias, T* Y, int ldy,
+template <typename T, int EPI, int NT = 4>
+__device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][4], const T* __restrict__ bias, T* Y, int ldy,
                                                const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                int mask_period, int M, int N, int mw0, int nw0, int lane) {
   constexpr bool kGelu = EPI & EPI_GELU, kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
   const int nq = (lane >> 4) * 4;
-  float bv[4][4];
+  float bv[NT][4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = nw0 + nt * 16 + nq + r;
@@ -79,10 +79,10 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[4][4], const T* __
     const int m = mw0 + mt * 16 + (lane & 15);
     const int mc = m < M ? m : M - 1;
     const float mk = kMask ? (row_mask[mc % mask_period] ? 1.f : 0.f) : 1.f;
-    Pack4<T> p1[4], p2[4];
+    Pack4<T> p1[NT], p2[NT];
     if (kR1) {   // N % 4 == 0 is guaranteed by mfma_linear_supported when a residual is given
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
         int nc = nw0 + nt * 16 + nq;
         nc = nc < n_last ? nc : n_last;
         p1[nt] = *reinterpret_cast<const Pack4<T>*>(R1 + static_cast<size_t>(mc) * ldr + nc);
@@ -90,7 +90,7 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[4][4], const T* __
       }
     }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
       const int n = nw0 + nt * 16 + nq;
       float v[4];
 #pragma unroll
@@ -716,6 +716,75 @@ __global__ __launch_bounds__(1024, 4) void gemm_mfma_128_ksplit(const T* __restr
 #undef D3PM_FOLD
 }
 
+
+// ---- variant 9: 128 x 64 tile (waves 2 x 2 of 64 x 32), single 24-KiB LDS stage, up to 6 workgroups per CU ------
+// For the N = 512 projections a 128 x 128 grid is a single lock-step round of 768 workgroups (3 per CU); half-width
+// tiles double the workgroups in flight (latency hiding) at 1.5x the L2 -> LDS bytes per flop.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 4) void gemm_mfma_128x64(const T* __restrict__ X, int ldx, const T* __restrict__ W,
+                                                           const T* __restrict__ bias, T* Y, int ldy, const T* R1,
+                                                           const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
+                                                           int mask_period, int M, int N, int K, int n_tiles) {
+  constexpr int TBN = 64, A_BYTES = BM * ROW_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
+  const int m0 = tile_m * BM, n0 = tile_n * TBN;
+
+  const T* gsrc[3];
+  int ldst[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = wave * 3 + i;               // 24 wave-instructions of 8 rows: 0..15 from X, 16..23 from W
+    const bool isA = j < 16;
+    const int row = (isA ? j : j - 16) * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    if (isA) {
+      int mr = m0 + row;
+      mr = mr < M ? mr : M - 1;
+      gsrc[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
+    } else {
+      int nr = n0 + row;
+      nr = nr < N ? nr : N - 1;
+      gsrc[i] = W + static_cast<size_t>(nr) * K + logical * 8;
+    }
+    ldst[i] = (isA ? 0 : A_BYTES) + (isA ? j : j - 16) * 1024;
+  }
+
+  floatx4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  const int nk = K / BK;
+  const char* bufA = smem;
+  const char* bufB = smem + A_BYTES;
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void)(gsrc[i] + kt * BK), (lds_void)(smem + ldst[i]), 16, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 fx[4], fw[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 32 + t * 16 + frow, ks * 4 + fch));
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
+    }
+    __syncthreads();
+  }
+  epilogue_store<T, EPI, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 32, lane);
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -747,9 +816,10 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   const bool latency = g_latency_gemm && a.M <= 1536 && a.K % (4 * BK) == 0 && g_gemm_variant == 2;
   const bool ffn_act = a.act == ACT_RELU || a.act == ACT_SILU;
   const int variant = ffn_act ? 2 : (latency ? 8 : g_gemm_variant);
-  const int tbm = (variant >= 4 && variant <= 6) ? 256 : BM, tbn = (variant == 5 || variant == 6) ? 256 : BN;
+  const int tbm = (variant >= 4 && variant <= 6) ? 256 : BM, tbn = (variant == 5 || variant == 6) ? 256 : (variant == 9 ? 64 : BN);
   const int n_tiles = (a.N + tbn - 1) / tbn, m_tiles = (a.M + tbm - 1) / tbm;
-  const size_t lds = variant == 8 ? 8 * TILE_BYTES
+  const size_t lds = variant == 9 ? (BM + 64) * ROW_BYTES
+                     : variant == 8 ? 8 * TILE_BYTES
                      : variant == 7 ? 2 * TILE_BYTES
                      : variant == 6 ? 2 * static_cast<size_t>(tbm + tbn) * ROW_BYTES
                      : variant >= 4 ? static_cast<size_t>(tbm + tbn) * ROW_BYTES
@@ -774,7 +844,8 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   } while (0)
 #define D3PM_GEMM_EPI(E)                                                        \
   do {                                                                          \
-    if (variant == 8) D3PM_GEMM(gemm_mfma_128_ksplit<U, E>);                    \
+    if (variant == 9) D3PM_GEMM(gemm_mfma_128x64<U, E>);                        \
+    else if (variant == 8) D3PM_GEMM(gemm_mfma_128_ksplit<U, E>);               \
     else if (variant == 7) D3PM_GEMM(gemm_mfma_128_k32<U, E>);                  \
     else if (variant == 6) D3PM_GEMM(gemm_mfma_big_pf<U, E, 4, 4>);             \
     else if (variant == 5) D3PM_GEMM(gemm_mfma_big<U, E, 4, 4, 4>);             \
