@@ -733,11 +733,11 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128x64(const T* __restrict__
   const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
   const int m0 = tile_m * BM, n0 = tile_n * TBN;
 
-  const T* gsrc[3];
-  int ldst[3];
+  const T* gsrc[6];
+  int ldst[6];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int j = wave * 3 + i;               // 24 wave-instructions of 8 rows: 0..15 from X, 16..23 from W
+  for (int i = 0; i < 6; ++i) {
+    const int j = wave * 6 + i;               // 24 wave-instructions of 8 rows: 0..15 from X, 16..23 from W
     const bool isA = j < 16;
     const int row = (isA ? j : j - 16) * 8 + (lane >> 3);
     const int logical = (lane & 7) ^ ((row >> 1) & 7);
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128x64(const T* __restrict__
   const char* bufB = smem + A_BYTES;
   for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 6; ++i)
       __builtin_amdgcn_global_load_lds((glb_void)(gsrc[i] + kt * BK), (lds_void)(smem + ldst[i]), 16, 0, 0);
     __syncthreads();
 #pragma unroll
