@@ -215,17 +215,11 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
                       int M, int d, float eps, void *stream);
 
 /* Tuning knobs (process-wide; defaults are what bench.py measures).
- * D3PM_TUNE_GEMM_VARIANT: 0 register-staged double buffer, 1 direct-to-LDS double buffer,
- *                         2 direct-to-LDS single buffer, 4 workgroups per CU (default),
- *                         3 direct-to-LDS issued from asm with the next K-tile in flight under the MFMAs,
- *                         4 / 5 = variant 2 with 256x128 / 256x256 workgroup tiles (8 / 16 waves),
- *                         6 = 256x256 tile, two LDS stages, asm DMA prefetch (1 workgroup of 16 waves per CU),
- *                         7 = 128x128 tile, K-step 32, two LDS stages, asm DMA prefetch, 4 workgroups per CU. */
-enum {
-  D3PM_TUNE_GEMM_VARIANT = 0,
-  D3PM_TUNE_ATTN_QUERY_GROUPS = 1, /* 16-query groups per wave: 1 (default) or 2 */
-  D3PM_TUNE_LATENCY_GEMM = 2       /* 1: GEMMs with M <= 1536 rows split K four ways inside the workgroup (default 0: measured slower) */
-};
+ * D3PM_TUNE_GEMM_VARIANT: 0 = auto (default): latency schedule for M <= 1536 rows, throughput schedule otherwise;
+ *                         2 = always the throughput schedule (one LDS stage, 4 workgroups per CU);
+ *                         3 = always the latency schedule (two stages, asm DMA prefetch).  Results are bit-identical.
+ * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention, 1 (default) or 2. */
+enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1 };
 int d3pm_set_tuning(int knob, int value);
 
 /* Timing hooks for bench.py's roofline object: when enabled, every launch of the kernel class

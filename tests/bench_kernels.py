@@ -46,12 +46,12 @@ def main():
         y = torch.empty(M, ldy, device=DEV, dtype=dtype)
         r = torch.randn(M, ldy, device=DEV).to(dtype) if res else None
         line = f"{name:10s} N={N:5d} K={K:5d}"
-        for variant in ((2,) if quick else (2, 9)):
+        for variant in ((2,) if quick else (2, 3)):
             _hip.set_gemm_variant(variant)
             t = timeit(lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=ldy))
             line += f" | v{variant}: {t * 1e6:7.1f} us {2 * M * N * K / t / 1e12:7.1f} TF/s"
         print(line, flush=True)
-    _hip.set_gemm_variant(2)
+    _hip.set_gemm_variant(0)
     if "--small" in sys.argv or not quick:
         Ms = 768
         print(f"# GEMM  M={Ms} (one utterance: latency regime)")
@@ -63,14 +63,12 @@ def main():
             y = torch.empty(Ms, ldy, device=DEV, dtype=dtype)
             r = torch.randn(Ms, ldy, device=DEV).to(dtype) if res else None
             line = f"{name:10s} N={N:5d} K={K:5d}"
-            for variant, lat in ((2, False), (2, True), (3, False)):
+            for variant in (2, 3):
                 _hip.set_gemm_variant(variant)
-                _hip.set_latency_gemm(lat)
                 t = timeit(lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=ldy), 50)
-                line += f" | v{variant}{'+ksplit' if lat else ''}: {t * 1e6:6.1f} us"
+                line += f" | v{variant}: {t * 1e6:6.1f} us"
             print(line, flush=True)
-        _hip.set_gemm_variant(2)
-        _hip.set_latency_gemm(False)
+        _hip.set_gemm_variant(0)
     print("# attention  B=32 H=8 hd=64")
     for name, Tq, S in (("self", 768, 768), ("text", 768, 50), ("prompt", 768, 225)):
         q = torch.randn(32, Tq, 512, device=DEV).to(dtype)

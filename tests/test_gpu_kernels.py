@@ -33,13 +33,13 @@ def gelu32(v):
     return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 7, 9], ids=lambda v: f"gemm_v{v}")
+@pytest.fixture(params=[2, 3], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency"}[v])
 def gemm_variant(request, built_lib):
-    """Every staging variant of the MFMA GEMM must pass the same numerics (the default is restored afterwards)."""
+    """Both schedules of the MFMA GEMM must pass the same numerics (auto selection is restored afterwards)."""
     from vall_e.vall_e import _hip
     _hip.set_gemm_variant(request.param)
     yield request.param
-    _hip.set_gemm_variant(2)
+    _hip.set_gemm_variant(0)
 
 
 @pytest.fixture(params=[1, 2], ids=lambda v: f"qg{v}")
@@ -96,6 +96,21 @@ def test_linear_epilogues(gemm_variant, dtype):
         outs[fam] = (y.float(), y2.float(), y3.float())
     for a, c in zip(outs[_hip.FAMILY_GENERIC], outs[_hip.FAMILY_MFMA]):
         assert (a == c).float().mean().item() > 0.97
+
+
+def test_gemm_schedules_are_bit_identical(built_lib):
+    """The latency and throughput schedules accumulate in the same order: choosing by M never changes a result."""
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(1536, 512, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(1536, 512, generator=g) / math.sqrt(512)).to(torch.bfloat16).to(DEV)
+    b = torch.randn(1536, generator=g).to(torch.bfloat16).to(DEV)
+    outs = []
+    for v in (2, 3):
+        _hip.set_gemm_variant(v)
+        outs.append(_hip.op_linear(x, w, b, act=1, family=_hip.FAMILY_MFMA).clone())
+    _hip.set_gemm_variant(0)
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_linear_fp32_generic(built_lib):

@@ -7,16 +7,26 @@
 // shape tiles (K % 64 == 0, 16-byte aligned rows); everything else goes to linear_tiled (generic).
 //
 // Structure (one workgroup = 4 wave64 = 128 x 128 output tile, K-step 64):
-//   * global -> registers -> LDS staging, 16 B per lane, next K-tile's loads issued before the
-//     current tile's MFMAs and written to the other LDS buffer after them (one barrier per K-tile);
-//   * LDS rows are 128 B (64 k); 16-B chunk c of row r lives at chunk c ^ ((r >> 1) & 7): both the
-//     ds_write_b128 of the staging pass and the ds_read_b128 of the MFMA fragments are bank-conflict
-//     free (checked exhaustively against the gfx950 lane groups);
+//   * direct-to-LDS staging (global_load_lds_dwordx4, 1 KiB per wave-instruction), no staging VGPRs;
+//   * LDS rows are 128 B (64 k); 16-B chunk c of row r lives at chunk c ^ ((r >> 1) & 7): applied to the
+//     per-lane SOURCE address of the DMA and undone on the ds_read_b128 fragment reads -- bank-conflict free
+//     (checked exhaustively against the gfx950 lane groups; SQ_LDS_BANK_CONFLICT = 0 in profiles/);
 //   * v_mfma_f32_16x16x32_{f16,bf16}: each wave owns 64 x 64 = 4 x 4 tiles, fp32 accumulators;
 //   * the MFMA is issued as D = W_frag . X_frag^T so that a lane ends up with 4 consecutive output
 //     columns of one row: bias / GELU / residual / mask run on registers and the store (and the
-//     residual loads) are 8 B per lane;
-//   * epilogue rounding points are the eager model's (see d3pm_kernels.h).
+//     residual loads) are 8 B per lane; epilogue rounding points are the eager model's (d3pm_kernels.h);
+//   * tiles are walked in an XCD-aware order (the n-tiles of one X panel share an L2).
+// Two schedules of the same arithmetic (bit-identical results):
+//   throughput (default): ONE 32-KiB LDS stage, two barriers per K-step, FOUR workgroups per CU hide each
+//       other's DMA latency -- 660 / 410 / 530 / 840 / 650 TFLOP/s on the qkv / proj / fc1 / fc2 / final shapes
+//       at M = 24576 (profiles/round1_*_microbench.txt);
+//   latency (M <= 1536, one or two utterances): two stages, the next K-tile's DMA issued from inline asm so
+//       that it stays in flight under the MFMAs (hipcc otherwise drains it before the first ds_read),
+//       counted vmcnt + raw s_barrier; ~10 % shorter kernels when a CU holds a single workgroup.
+// Measured and rejected in round 1 (same tests, same shapes; numbers in DESIGN.md §3): register staging
+// (scratch spills, 200 TF/s), 256x128 / 256x256 tiles with 8 / 16 waves (480-530), 256x256 two-stage prefetch
+// (450), K-step 32 two-stage prefetch at 4 workgroups per CU (550), 128x64 tiles at 6 per CU (550),
+// K split four ways inside a 16-wave workgroup for M = 768 (slower: the fixed per-kernel cost dominates).
 // M and N tails are handled by clamped loads and predicated stores; K must be a multiple of 64.
 #include "d3pm_kernels.h"
 
@@ -120,101 +130,16 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][4], const T* _
   }
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_128(const T* __restrict__ X, int ldx, const T* __restrict__ W,
-                                                        const T* __restrict__ bias, T* Y, int ldy, const T* R1,
-                                                        const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                                        int mask_period, int M, int N, int K, int n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // staging assignment: 4 x 16 B of the X tile and 4 x 16 B of the W tile per thread
-  const T* gx[4];
-  const T* gw[4];
-  int soff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-    int mr = m0 + row, nr = n0 + row;
-    mr = mr < M ? mr : M - 1;
-    nr = nr < N ? nr : N - 1;
-    gx[i] = X + static_cast<size_t>(mr) * ldx + ch * 8;
-    gw[i] = W + static_cast<size_t>(nr) * K + ch * 8;
-    soff[i] = lds_off(row, ch);
-  }
-  uint4 rx[4], rw[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    rx[i] = *reinterpret_cast<const uint4*>(gx[i]);
-    rw[i] = *reinterpret_cast<const uint4*>(gw[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<uint4*>(smem + soff[i]) = rx[i];
-    *reinterpret_cast<uint4*>(smem + TILE_BYTES + soff[i]) = rw[i];
-  }
-  __syncthreads();
-
-  floatx4 acc[4][4];   // [nt][mt]: rows of D index n, columns index m
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fch = lane >> 4;
-  const int nk = K / BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* bufA = smem + (kt & 1) * 2 * TILE_BYTES;
-    const char* bufB = bufA + TILE_BYTES;
-    const bool more = kt + 1 < nk;
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rx[i] = *reinterpret_cast<const uint4*>(gx[i] + (kt + 1) * BK);
-        rw[i] = *reinterpret_cast<const uint4*>(gw[i] + (kt + 1) * BK);
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint4 fx[4], fw[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
-        fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 64 + t * 16 + frow, ks * 4 + fch));
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
-    }
-    if (more) {
-      char* nb = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<uint4*>(nb + soff[i]) = rx[i];
-        *reinterpret_cast<uint4*>(nb + TILE_BYTES + soff[i]) = rw[i];
-      }
-    }
-    __syncthreads();
-  }
-
-  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
-}
-
-
-// ---- variant 2: direct-to-LDS staging (global_load_lds_dwordx4) -------------------------------------
+// ---- throughput schedule: direct-to-LDS staging (global_load_lds_dwordx4) ---------------------------------
 // Each wave-instruction lands 1 KiB = 8 rows x 128 B linearly in LDS (wave-uniform base + lane*16), so the
 // XOR swizzle is applied to the per-lane SOURCE address (logical chunk = lane&7 ^ f(row)) and undone by the
 // same lds_off() on the fragment reads.  No staging VGPRs, no ds_write pass.
 typedef __attribute__((address_space(3))) void* lds_void;
 typedef const __attribute__((address_space(1))) void* glb_void;
 
-template <typename T, int EPI, int NBUF>   // NBUF 2: next tile's DMA issued before the MFMAs; NBUF 1: 32 KiB LDS, 4 workgroups per CU
-__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_mfma_128_glds(const T* __restrict__ X, int ldx, const T* __restrict__ W,
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 4) void gemm_mfma_128_glds(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                              const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                              const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                              int mask_period, int M, int N, int K, int n_tiles) {
@@ -245,11 +170,6 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_mfma_128_glds(con
       __builtin_amdgcn_global_load_lds((glb_void)(gw[i] + kt * BK), (lds_void)(base + TILE_BYTES + i * 1024), 16, 0, 0);
     }
   };
-  if (NBUF == 2) {
-    issue(0, 0);
-    __syncthreads();
-  }
-
   floatx4 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -259,14 +179,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_mfma_128_glds(con
   const int frow = lane & 15, fch = lane >> 4;
   const int nk = K / BK;
   for (int kt = 0; kt < nk; ++kt) {
-    const char* bufA = smem + (NBUF == 2 ? (kt & 1) : 0) * 2 * TILE_BYTES;
+    const char* bufA = smem;
     const char* bufB = bufA + TILE_BYTES;
-    if (NBUF == 2) {
-      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    } else {
-      issue(kt, 0);
-      __syncthreads();
-    }
+    issue(kt, 0);
+    __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the tile
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 fx[4], fw[4];
@@ -286,7 +202,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_mfma_128_glds(con
 }
 
 
-// ---- variant 3: direct-to-LDS staging issued from inline asm, next tile in flight under the MFMAs ------
+// ---- latency schedule: direct-to-LDS staging issued from inline asm, next tile in flight under the MFMAs ---
 // hipcc cannot tell an in-flight LDS-DMA from the LDS reads of the tile being computed and drains it
 // (vmcnt(0)) before the first ds_read; issuing the DMA from asm keeps it out of the compiler's counters, so
 // the wait is placed by hand: counted vmcnt (8 DMAs per wave per tile stay in flight), raw s_barrier.
@@ -374,417 +290,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128_pf(const T* __restrict__
   epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
-
-// ---- variants 4/5: larger workgroup tiles (WGM x WGN waves of 64 x 64) -------------------------------
-// L2 -> LDS operand traffic per flop scales with (1/BM + 1/BN); at 128 x 128 it is the first-order limiter
-// (a CU takes in ~70-135 GB/s from its XCD's L2).  Same single-buffer direct-to-LDS structure as variant 2.
-template <typename T, int EPI, int WGM, int WGN, int MINW>
-__global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_mfma_big(const T* __restrict__ X, int ldx,
-                                                                     const T* __restrict__ W,
-                                                                     const T* __restrict__ bias, T* Y, int ldy,
-                                                                     const T* R1, const T* R2, int ldr,
-                                                                     const uint8_t* __restrict__ row_mask,
-                                                                     int mask_period, int M, int N, int K, int n_tiles) {
-  constexpr int TBM = 64 * WGM, TBN = 64 * WGN, NW = WGM * WGN;
-  constexpr int A_BYTES = TBM * ROW_BYTES;
-  constexpr int A_INSTR = TBM / 8, B_INSTR = TBN / 8, PER_WAVE = (A_INSTR + B_INSTR) / NW;
-  static_assert((A_INSTR + B_INSTR) % NW == 0, "staging instructions must divide evenly over the waves");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
-  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
-
-  // wave-instruction j (0 .. A_INSTR+B_INSTR-1) stages 8 rows: j < A_INSTR from X, else from W
-  const T* gsrc[PER_WAVE];
-  int ldst[PER_WAVE];
-#pragma unroll
-  for (int i = 0; i < PER_WAVE; ++i) {
-    const int j = wave * PER_WAVE + i;
-    const bool isA = j < A_INSTR;
-    const int row = (isA ? j : j - A_INSTR) * 8 + (lane >> 3);
-    const int logical = (lane & 7) ^ ((row >> 1) & 7);
-    if (isA) {
-      int mr = m0 + row;
-      mr = mr < M ? mr : M - 1;
-      gsrc[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
-    } else {
-      int nr = n0 + row;
-      nr = nr < N ? nr : N - 1;
-      gsrc[i] = W + static_cast<size_t>(nr) * K + logical * 8;
-    }
-    ldst[i] = (isA ? 0 : A_BYTES) + (isA ? j : j - A_INSTR) * 1024;
-  }
-
-  floatx4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fch = lane >> 4;
-  const int nk = K / BK;
-  const char* bufA = smem;
-  const char* bufB = smem + A_BYTES;
-  for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void)(gsrc[i] + kt * BK), (lds_void)(smem + ldst[i]), 16, 0, 0);
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint4 fx[4], fw[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
-        fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 64 + t * 16 + frow, ks * 4 + fch));
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
-    }
-    __syncthreads();
-  }
-  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
-}
-
-
-// ---- variant 6: 256 x 256 tile, 16 waves, two LDS stages, asm DMA prefetch (1 workgroup per CU) ----------
-// Half the L2 -> LDS bytes per flop of the 128 x 128 tile; the next K-tile's DMA (4 x 1 KiB per wave) is in
-// flight under the current tile's MFMAs (counted vmcnt + raw barriers as in variant 3).
-template <typename T, int EPI, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void gemm_mfma_big_pf(
-    const T* __restrict__ X, int ldx, const T* __restrict__ W, const T* __restrict__ bias, T* Y, int ldy, const T* R1,
-    const T* R2, int ldr, const uint8_t* __restrict__ row_mask, int mask_period, int M, int N, int K, int n_tiles) {
-  constexpr int TBM = 64 * WGM, TBN = 64 * WGN, NW = WGM * WGN;
-  constexpr int A_BYTES = TBM * ROW_BYTES, STAGE = (TBM + TBN) * ROW_BYTES;
-  constexpr int A_INSTR = TBM / 8, B_INSTR = TBN / 8, PER_WAVE = (A_INSTR + B_INSTR) / NW;
-  static_assert((A_INSTR + B_INSTR) % NW == 0, "staging instructions must divide evenly over the waves");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
-  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
-  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
-
-  const T* gsrc[PER_WAVE];
-  uint32_t ldst[PER_WAVE];
-#pragma unroll
-  for (int i = 0; i < PER_WAVE; ++i) {
-    const int j = wave * PER_WAVE + i;
-    const bool isA = j < A_INSTR;
-    const int row = (isA ? j : j - A_INSTR) * 8 + (lane >> 3);
-    const int logical = (lane & 7) ^ ((row >> 1) & 7);
-    if (isA) {
-      int mr = m0 + row;
-      mr = mr < M ? mr : M - 1;
-      gsrc[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
-    } else {
-      int nr = n0 + row;
-      nr = nr < N ? nr : N - 1;
-      gsrc[i] = W + static_cast<size_t>(nr) * K + logical * 8;
-    }
-    ldst[i] = lds_base + (isA ? 0 : A_BYTES) + (isA ? j : j - A_INSTR) * 1024;
-  }
-  auto issue = [&](int kt, int buf) {
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) glds16_asm(gsrc[i] + kt * BK, ldst[i] + buf * STAGE);
-  };
-
-  floatx4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fch = lane >> 4;
-  const int nk = K / BK;
-  issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* bufA = smem + (kt & 1) * STAGE;
-    const char* bufB = bufA + A_BYTES;
-    if (kt + 1 < nk) {
-      issue(kt + 1, (kt + 1) & 1);
-      if (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint4 fx[4], fw[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
-        fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 64 + t * 16 + frow, ks * 4 + fch));
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
-}
-
-
-// ---- variant 7: 128 x 128 tile, K-step 32, two 16-KiB LDS stages, asm DMA prefetch, 4 workgroups per CU ------
-// PMC on variant 2 (qkv shape): 42 % of the wave cycles wait on the DMA + barrier, 43 % are MFMA issue stalls,
-// MFMA pipe 26 % busy -- the four co-resident workgroups drift into the same phase.  Here every wave keeps
-// its own next K-step in flight under its MFMAs AND four workgroups share the CU.
-// LDS rows are 64 B (32 k): chunk c of row r lives at c ^ (((r >> 3) & 1) * 3) -- conflict-free ds_read_b128.
-__device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) * 3)) << 4); }
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(256, 4) void gemm_mfma_128_k32(const T* __restrict__ X, int ldx, const T* __restrict__ W,
-                                                            const T* __restrict__ bias, T* Y, int ldy, const T* R1,
-                                                            const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                                            int mask_period, int M, int N, int K, int n_tiles) {
-  constexpr int STAGE = 2 * BM * 64;   // A tile 8 KiB | B tile 8 KiB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
-
-  const T* gsrc[4];
-  uint32_t ldst[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = wave * 4 + i;                    // 16 wave-instructions of 16 rows: 0..7 from X, 8..15 from W
-    const bool isA = j < 8;
-    const int row = (j & 7) * 16 + (lane >> 2);
-    const int logical = (lane & 3) ^ (((row >> 3) & 1) * 3);
-    if (isA) {
-      int mr = m0 + row;
-      mr = mr < M ? mr : M - 1;
-      gsrc[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
-    } else {
-      int nr = n0 + row;
-      nr = nr < N ? nr : N - 1;
-      gsrc[i] = W + static_cast<size_t>(nr) * K + logical * 8;
-    }
-    ldst[i] = lds_base + (isA ? 0 : BM * 64) + (j & 7) * 1024;
-  }
-  auto issue = [&](int kt, int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16_asm(gsrc[i] + kt * 32, ldst[i] + buf * STAGE);
-  };
-
-  floatx4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fch = lane >> 4;
-  const int nk = K / 32;
-  issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* bufA = smem + (kt & 1) * STAGE;
-    const char* bufB = bufA + BM * 64;
-    if (kt + 1 < nk) {
-      issue(kt + 1, (kt + 1) & 1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    uint4 fx[4], fw[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off32(wm * 64 + t * 16 + frow, fch));
-      fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off32(wn * 64 + t * 16 + frow, fch));
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
-}
-
-
-// ---- variant 8: latency GEMM for one or two utterances (M <= 1536): 16 waves, K split 4 ways INSIDE the workgroup --
-// At M = 768 a 128 x 128 grid has 24-96 workgroups on 256 CUs and every kernel is a serial chain of K/64
-// DMA -> barrier -> MFMA steps (~0.75 us each).  Here four 4-wave groups of one workgroup each own a quarter of K
-// (own 32-KiB LDS tiles, so four times the DMA bytes are in flight per CU and the chain is four times shorter) and
-// the partial accumulators are folded through LDS in a fixed order ((s0+s2)+(s1+s3)) before the usual epilogue.
-template <typename T, int EPI>
-__global__ __launch_bounds__(1024, 4) void gemm_mfma_128_ksplit(const T* __restrict__ X, int ldx, const T* __restrict__ W,
-                                                                const T* __restrict__ bias, T* Y, int ldy, const T* R1,
-                                                                const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                                                int mask_period, int M, int N, int K, int n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slices x (A tile | B tile) = 128 KiB
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: slice branches below are s_cbranch
-  const int slice = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  char* my = smem + slice * 2 * TILE_BYTES;
-
-  const T* gx[4];
-  const T* gw[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (w4 * 4 + i) * 8 + (lane >> 3);
-    const int logical = (lane & 7) ^ ((row >> 1) & 7);
-    int mr = m0 + row, nr = n0 + row;
-    mr = mr < M ? mr : M - 1;
-    nr = nr < N ? nr : N - 1;
-    gx[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
-    gw[i] = W + static_cast<size_t>(nr) * K + logical * 8;
-  }
-
-  floatx4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fch = lane >> 4;
-  const int steps = K / BK / 4, k_first = slice * steps;
-  const char* bufA = my;
-  const char* bufB = my + TILE_BYTES;
-  for (int kt = 0; kt < steps; ++kt) {
-    char* base = my + (w4 * 4) * 1024;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void)(gx[i] + (k_first + kt) * BK), (lds_void)(base + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void)(gw[i] + (k_first + kt) * BK), (lds_void)(base + TILE_BYTES + i * 1024), 16, 0, 0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint4 fx[4], fw[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
-        fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 64 + t * 16 + frow, ks * 4 + fch));
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
-    }
-    __syncthreads();
-  }
-  // fold the four partial tiles: regions of 16 KiB = one wave's 16 x float4 per lane
-#define D3PM_REGION(idx) (reinterpret_cast<floatx4*>(smem + (idx) * 16384) + lane)
-#define D3PM_SPILL(r)                                                                       \
-  do {                                                                                      \
-    floatx4* r_ = (r);                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) r_[i * 64] = acc[i >> 2][i & 3];         \
-  } while (0)
-#define D3PM_FOLD(r)                                                                        \
-  do {                                                                                      \
-    const floatx4* r_ = (r);                                                                \
-    _Pragma("unroll") for (int i = 0; i < 16; i += 4) {                                     \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[(i + j) >> 2][(i + j) & 3] += r_[(i + j) * 64]; \
-      __builtin_amdgcn_sched_barrier(0);                                                    \
-    }                                                                                       \
-  } while (0)
-  if (slice >= 2) D3PM_SPILL(D3PM_REGION((slice - 2) * 4 + w4));
-  __syncthreads();
-  if (slice < 2) D3PM_FOLD(D3PM_REGION(slice * 4 + w4));
-  __syncthreads();
-  if (slice == 1) D3PM_SPILL(D3PM_REGION(w4));
-  __syncthreads();
-  if (slice == 0) {
-    D3PM_FOLD(D3PM_REGION(w4));
-    epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
-  }
-#undef D3PM_REGION
-#undef D3PM_SPILL
-#undef D3PM_FOLD
-}
-
-
-// ---- variant 9: 128 x 64 tile (waves 2 x 2 of 64 x 32), single 24-KiB LDS stage, up to 6 workgroups per CU ------
-// For the N = 512 projections a 128 x 128 grid is a single lock-step round of 768 workgroups (3 per CU); half-width
-// tiles double the workgroups in flight (latency hiding) at 1.5x the L2 -> LDS bytes per flop.
-template <typename T, int EPI>
-__global__ __launch_bounds__(256, 4) void gemm_mfma_128x64(const T* __restrict__ X, int ldx, const T* __restrict__ W,
-                                                           const T* __restrict__ bias, T* Y, int ldy, const T* R1,
-                                                           const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                                           int mask_period, int M, int N, int K, int n_tiles) {
-  constexpr int TBN = 64, A_BYTES = BM * ROW_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
-  const int m0 = tile_m * BM, n0 = tile_n * TBN;
-
-  const T* gsrc[6];
-  int ldst[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int j = wave * 6 + i;               // 24 wave-instructions of 8 rows: 0..15 from X, 16..23 from W
-    const bool isA = j < 16;
-    const int row = (isA ? j : j - 16) * 8 + (lane >> 3);
-    const int logical = (lane & 7) ^ ((row >> 1) & 7);
-    if (isA) {
-      int mr = m0 + row;
-      mr = mr < M ? mr : M - 1;
-      gsrc[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
-    } else {
-      int nr = n0 + row;
-      nr = nr < N ? nr : N - 1;
-      gsrc[i] = W + static_cast<size_t>(nr) * K + logical * 8;
-    }
-    ldst[i] = (isA ? 0 : A_BYTES) + (isA ? j : j - 16) * 1024;
-  }
-
-  floatx4 acc[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fch = lane >> 4;
-  const int nk = K / BK;
-  const char* bufA = smem;
-  const char* bufB = smem + A_BYTES;
-  for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void)(gsrc[i] + kt * BK), (lds_void)(smem + ldst[i]), 16, 0, 0);
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint4 fx[4], fw[2];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fx[t] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + t * 16 + frow, ks * 4 + fch));
-#pragma unroll
-      for (int t = 0; t < 2; ++t) fw[t] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 32 + t * 16 + frow, ks * 4 + fch));
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
-    }
-    __syncthreads();
-  }
-  epilogue_store<T, EPI, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 32, lane);
-}
-
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -797,7 +302,7 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   if (a.R2 && !aligned(a.R2, 8)) return false;
   if (static_cast<long long>(a.M) * a.N < 128 * 128) return false;     // not worth a 128^2 tile
   const bool gelu = a.act == ACT_GELU, r1 = a.R1 != nullptr, r2 = a.R2 != nullptr, mk = a.row_mask != nullptr;
-  if (a.act == ACT_RELU || a.act == ACT_SILU) return !r1 && !mk;   // condition-encoder FFN epilogues (default variant only)
+  if (a.act == ACT_RELU || a.act == ACT_SILU) return !r1 && !mk;   // condition-encoder FFN epilogues
   if (r2 && !r1) return false;
   // instantiated epilogues: plain, GELU, R1, R1+R2, R1+mask
   if (gelu && (r1 || mk)) return false;
@@ -805,26 +310,16 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
-static bool g_latency_gemm = false;   // measured slower than variant 2 at M = 768 (13-17 us vs 11-13 us): per-kernel fixed cost, not the K chain, dominates
-void set_latency_gemm(int on) { g_latency_gemm = on != 0; }
-static int g_gemm_variant = 2;   // 0 register staging, 1 direct-to-LDS 2 buffers, 2 direct-to-LDS 1 buffer (4 WG/CU), 3 asm DMA prefetch
+static int g_gemm_variant = 0;   // 0 auto (latency schedule for M <= 1536, else throughput), 2 throughput, 3 latency
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
-  // one or two utterances: latency regime -> K split inside the workgroup (variant 8).  The rule looks at M
-  // only, so that every batch of >= 3 utterances takes the same kernels (bitwise batch / rank invariance).
-  const bool latency = g_latency_gemm && a.M <= 1536 && a.K % (4 * BK) == 0 && g_gemm_variant == 2;
+  // Both schedules accumulate in the same order, so the choice never changes a bit of the result.
   const bool ffn_act = a.act == ACT_RELU || a.act == ACT_SILU;
-  const int variant = ffn_act ? 2 : (latency ? 8 : g_gemm_variant);
-  const int tbm = (variant >= 4 && variant <= 6) ? 256 : BM, tbn = (variant == 5 || variant == 6) ? 256 : (variant == 9 ? 64 : BN);
-  const int n_tiles = (a.N + tbn - 1) / tbn, m_tiles = (a.M + tbm - 1) / tbm;
-  const size_t lds = variant == 9 ? (BM + 64) * ROW_BYTES
-                     : variant == 8 ? 8 * TILE_BYTES
-                     : variant == 7 ? 2 * TILE_BYTES
-                     : variant == 6 ? 2 * static_cast<size_t>(tbm + tbn) * ROW_BYTES
-                     : variant >= 4 ? static_cast<size_t>(tbm + tbn) * ROW_BYTES
-                                  : (variant == 2 ? 2 : 4) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
-  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block((variant == 5 || variant == 6 || variant == 8) ? 1024 : (variant == 4 ? 512 : 256));
+  const bool latency = !ffn_act && (g_gemm_variant == 3 || (g_gemm_variant == 0 && a.M <= 1536));
+  const int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
+  const size_t lds = (latency ? 4 : 2) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
+  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(256);
   const int epi = (a.act == ACT_GELU ? EPI_GELU : a.act == ACT_RELU ? EPI_RELU : a.act == ACT_SILU ? EPI_SILU : 0) |
                   (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
 
@@ -833,7 +328,7 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
       D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),                           \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES));          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));          \
       attr_set = true;                                                                                          \
     }                                                                                                           \
     __VA_ARGS__<<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),        \
@@ -842,29 +337,21 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
                                          a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles);                    \
     return D3PM_OK;                                                                                             \
   } while (0)
-#define D3PM_GEMM_EPI(E)                                                        \
-  do {                                                                          \
-    if (variant == 9) D3PM_GEMM(gemm_mfma_128x64<U, E>);                        \
-    else if (variant == 8) D3PM_GEMM(gemm_mfma_128_ksplit<U, E>);               \
-    else if (variant == 7) D3PM_GEMM(gemm_mfma_128_k32<U, E>);                  \
-    else if (variant == 6) D3PM_GEMM(gemm_mfma_big_pf<U, E, 4, 4>);             \
-    else if (variant == 5) D3PM_GEMM(gemm_mfma_big<U, E, 4, 4, 4>);             \
-    else if (variant == 4) D3PM_GEMM(gemm_mfma_big<U, E, 4, 2, 4>);             \
-    else if (variant == 3) D3PM_GEMM(gemm_mfma_128_pf<U, E>);                   \
-    else if (variant == 2) D3PM_GEMM(gemm_mfma_128_glds<U, E, 1>);              \
-    else if (variant == 1) D3PM_GEMM(gemm_mfma_128_glds<U, E, 2>);              \
-    else D3PM_GEMM(gemm_mfma_128<U, E>);                                        \
+#define D3PM_GEMM_EPI(E)                                  \
+  do {                                                    \
+    if (latency) D3PM_GEMM(gemm_mfma_128_pf<U, E>);       \
+    else D3PM_GEMM(gemm_mfma_128_glds<U, E>);             \
   } while (0)
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
-    switch (epi) {   // the epilogues the denoiser uses
+    switch (epi) {   // the epilogues the denoiser and the condition encoders use
       case 0: D3PM_GEMM_EPI(0);
       case EPI_GELU: D3PM_GEMM_EPI(EPI_GELU);
       case EPI_R1: D3PM_GEMM_EPI(EPI_R1);
       case EPI_R2: D3PM_GEMM_EPI(EPI_R2);
       case EPI_R1 | EPI_MASK: D3PM_GEMM_EPI(EPI_R1 | EPI_MASK);
-      case EPI_RELU: if (variant == 2) D3PM_GEMM(gemm_mfma_128_glds<U, EPI_RELU, 1>); break;
-      case EPI_SILU: if (variant == 2) D3PM_GEMM(gemm_mfma_128_glds<U, EPI_SILU, 1>); break;
+      case EPI_RELU: D3PM_GEMM(gemm_mfma_128_glds<U, EPI_RELU>);
+      case EPI_SILU: D3PM_GEMM(gemm_mfma_128_glds<U, EPI_SILU>);
       default: break;
     }
     return D3PM_E_SHAPE;

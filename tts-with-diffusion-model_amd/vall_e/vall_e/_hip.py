@@ -364,10 +364,6 @@ def set_gemm_variant(v: int):
     check(lib().d3pm_set_tuning(0, v), "d3pm_set_tuning")
 
 
-def set_latency_gemm(on: bool):
-    check(lib().d3pm_set_tuning(2, 1 if on else 0), "d3pm_set_tuning")
-
-
 def set_attn_query_groups(v: int):
     check(lib().d3pm_set_tuning(1, v), "d3pm_set_tuning")
 
