@@ -392,3 +392,27 @@ def test_full_size_libritts_properties():
     err = (la.float() - lg.float()).abs().max().item()
     REPORT["libritts_bf16_mfma_vs_generic_logits_max_abs_err"] = err
     assert err < 0.15
+
+
+def test_vctk_long_prompt_config_runs():
+    """BASELINE.json configs[3]: 750 prompt keys, 375 live frames on a 384 canvas, 200-step
+    schedule (the closed-form scalars for 200 steps are pinned to the reference in tests/golden/tables_t200.npz).
+    Determinism, id range, MFMA-vs-generic logits, and the first iteration starts at t = 199."""
+    from vall_e.vall_e import _hip, synth
+    cfg = synth.D3PMConfig.vctk_long_prompt()
+    m = make_model(cfg, synth.make_state_dict(cfg, 0), torch.bfloat16)
+    texts, proms = synth.make_inputs(cfg, 2, 1)
+    a, trace = m.generate_audio(texts, proms, steps=None, seed=3, return_trace=True)
+    assert a.shape == (2, cfg.canvas) and trace.shape == (199, 2, cfg.canvas)
+    assert int(a.min()) >= 0 and int(a.max()) <= 1024
+    assert (a[:, cfg.n_frames:] == trace[-1].long()[:, cfg.n_frames:]).all()
+    assert torch.equal(a, m.generate_audio(texts, proms, seed=3))
+    masked = (trace[:, :, :cfg.n_frames] == cfg.mask_id).sum(dim=(1, 2)).cpu()
+    assert masked[0] > masked[-1]                      # frames unmask over the 199 iterations
+    smp = m.sampler()
+    ct, cp = m.encode_conditions(texts, proms)
+    kv_t, kv_p = smp.cond_kv(ct, cp)
+    x, fm = m.canvas_init(2)
+    la, _ = smp.denoise(x, fm, 150, kv_t, kv_p)
+    lg, _ = smp.denoise(x, fm, 150, kv_t, kv_p, flags=_hip.FLAG_FORCE_GENERIC)
+    assert (la.float() - lg.float()).abs().max().item() < 0.15
