@@ -18,6 +18,8 @@ Fixtures
                         posterior rows, sampled x_{t-1}
     native_loop.npz     full shared-noise reverse process trajectories (fp16), 2 noise seeds,
                         + the 10-step "plumbing" run, + greedy runs (plain and final.weight x30)
+    nar_small.npz       stock NAR (levels 1..7) at d=128/2 heads/2 layers, two ragged utterances: response-row
+                        logits at levels 0 and 3 (fp32, fp16), full generation under torch seed 0
     wide_step.npz       the reference's own classes re-instantiated at d=512,H=8,L=6 (SURVEY §8c vi)
 """
 from __future__ import annotations
@@ -344,6 +346,58 @@ def gen_wide(out, m):
     np.savez_compressed(os.path.join(out, "wide_step.npz"), **res)
 
 
+def gen_nar(out):
+    """Stock NAR (nar.py / base.py) at a small size (d=128, 2 heads of 64, 2 layers), two ragged utterances:
+    logits of the response rows at quantizer levels 0 and 3 (fp32 and fp16) and the full 7-level generation under
+    torch seed 0.  The oracle must reproduce the reference bit for bit, Categorical draws included."""
+    import importlib.util
+    from oracle import nar_oracle as N
+    rh.load_reference_modules()
+    spec = importlib.util.spec_from_file_location(rh._PKG + ".nar", os.path.join(rh.REF_ROOT, "vall_e", "vall_e", "nar.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[rh._PKG + ".nar"] = mod
+    spec.loader.exec_module(mod)
+    cfg = synth.NARConfig(d_model=128, n_heads=2, n_layers=2)
+    sd32 = synth.make_nar_state_dict(cfg, W_SEED)
+    m = mod.NAR(cfg.n_tokens, d_model=cfg.d_model, n_heads=cfg.n_heads, n_layers=cfg.n_layers).eval()
+    m.load_state_dict(sd32)
+    texts, proms, resps = synth.make_nar_inputs(2, IN_SEED)
+    texts3, proms3, resps3 = synth.make_nar_inputs(2, IN_SEED, n_levels=4)
+    res = {}
+    for tag, dtype in (("f32", torch.float32), ("f16", torch.float16)):
+        mm = m.half() if dtype == torch.float16 else m.float()
+        sd = {k: v.to(dtype) for k, v in sd32.items()}
+        conv = (lambda a: a.numpy()) if dtype == torch.float32 else bits16
+        for lvl, (tx, pr, rs) in ((0, (texts, proms, resps)), (3, (texts3, proms3, resps3))):
+            # the reference's Base.forward up to the classifier (base.py:441-458), its own statements
+            with torch.no_grad():
+                x_list = mm._samplewise_merge_tensors(mm.text_emb(tx), mm.proms_emb(pr), mm.resps_emb(rs), sep=mm.sep)
+                import importlib
+                base = sys.modules[rh._PKG + ".base"]
+                x, msk = base.list_to_tensor(x_list)
+                x = mm.sin_emb.add_pe(x)
+                ql = torch.full((len(tx),), lvl)
+                for blk in mm.blocks:
+                    x = blk(x, msk, ql)
+                h = mm.classifier(x) * msk
+                ref = [h[b, len(x_list[b]) - len(rs[b]): len(x_list[b])] for b in range(len(tx))]
+                mine = N.level_logits(sd, cfg.n_heads, cfg.n_layers, tx, pr, rs, lvl)
+            for a, b_ in zip(ref, mine):
+                assert torch.equal(a, b_), (tag, lvl)
+            for b in range(len(tx)):
+                res[f"logits_l{lvl}_utt{b}_{tag}"] = conv(torch.cat([ref[b][:8], ref[b][-8:]]))
+        torch.manual_seed(0)
+        with torch.no_grad():
+            y = mm(texts, proms, resps, sampling_temperature=0.2)
+        torch.manual_seed(0)
+        yo = N.generate(sd, cfg.n_heads, cfg.n_layers, texts, proms, resps, 0.2, sampler="torch")
+        assert all(torch.equal(a, b_) for a, b_ in zip(y, yo))
+        for b in range(2):
+            res[f"generated_seed0_utt{b}_{tag}"] = y[b].numpy().astype(np.int16)
+    np.savez_compressed(os.path.join(out, "nar_small.npz"), **res)
+    print("  nar: oracle == reference (logits levels 0/3, 7-level generation under torch seed 0)")
+
+
 def main():
     assert rh.reference_available(), "needs /root/reference (build container only)"
     torch.manual_seed(0)
@@ -352,6 +406,7 @@ def main():
     print("tables (200 steps) ..."); gen_tables_t200(out)
     print("native ..."); gen_native(out, m)
     print("wide ...");   gen_wide(out, m)
+    print("nar ...");    gen_nar(out)
     with open(os.path.join(out, "FINGERPRINT.txt"), "w") as f:
         f.write(fingerprint() + "\n")
     print("done:", fingerprint())

@@ -149,3 +149,67 @@ def make_inputs(cfg: D3PMConfig, batch: int, seed: int = 1):
         m = int(rng.integers(cfg.s_prompt // 2, cfg.s_prompt + 1))
         proms.append(torch.from_numpy(rng.integers(0, 1024, size=(m, cfg.n_levels)).astype(np.int64)))
     return texts, proms
+
+
+# ---- stock NAR model (quantizer levels 1..7 after the D3PM sampler) ----------------------
+@dataclasses.dataclass(frozen=True)
+class NARConfig:
+    """Shapes of /root/reference/vall_e/vall_e/nar.py `NAR(Base)`; the registry builds d=1024, 16 heads, 12 layers
+    (`-half`: 512/8/12, `-quarter`: 256/4/12; vall_e/vall_e/__init__.py:34-57): head_dim is 64 in all of them."""
+    d_model: int = 1024
+    n_heads: int = 16
+    n_layers: int = 12
+    n_tokens: int = 1024
+    n_prom_levels: int = 8
+    n_resp_levels: int = 7
+
+    @property
+    def head_dim(self) -> int:
+        return self.d_model // self.n_heads
+
+
+def nar_state_dict_spec(cfg: NARConfig) -> dict[str, tuple[int, ...]]:
+    d, K = cfg.d_model, cfg.n_tokens
+    spec = {"sep": (d,), "text_emb.weight": (K, d), "proms_emb.weight": (cfg.n_prom_levels, K, d),
+            "resps_emb.weight": (cfg.n_resp_levels, K, d), "classifier.weight": (K, d), "classifier.bias": (K,)}
+    for i in range(cfg.n_layers):
+        p = f"blocks.{i}"
+        spec[f"{p}.attn.block.to_qkv.weight"] = (3 * d, d)
+        spec[f"{p}.attn.block.to_out.weight"] = (d, d)
+        spec[f"{p}.attn.block.to_out.bias"] = (d,)
+        spec[f"{p}.attn.norm.emb.weight"] = (cfg.n_resp_levels, 2 * d)
+        spec[f"{p}.ffn.block.0.weight"] = (4 * d, d)
+        spec[f"{p}.ffn.block.0.bias"] = (4 * d,)
+        spec[f"{p}.ffn.block.3.weight"] = (d, 4 * d)
+        spec[f"{p}.ffn.block.3.bias"] = (d,)
+        spec[f"{p}.ffn.norm.emb.weight"] = (cfg.n_resp_levels, 2 * d)
+    return spec
+
+
+def make_nar_state_dict(cfg: NARConfig, seed: int = 0) -> dict[str, torch.Tensor]:
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    out = {}
+    spec = nar_state_dict_spec(cfg)
+    for key in sorted(spec):
+        shape = spec[key]
+        if key.endswith("_emb.weight") or key == "sep":
+            w = rng.standard_normal(shape)
+        elif key.endswith("norm.emb.weight"):
+            w = 0.1 * rng.standard_normal(shape)         # upstream initialises AdaLN to zeros; non-zero exercises it
+        else:
+            fan_in = shape[-1] if key.endswith("weight") else spec[key[:-4] + "weight"][-1]
+            a = 1.0 / math.sqrt(fan_in)
+            w = rng.uniform(-a, a, shape)
+        out[key] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
+    return out
+
+
+def make_nar_inputs(batch: int, seed: int = 1, t_text=(8, 16), t_prom=(20, 32), t_resp=(30, 44), n_levels: int = 1):
+    """Ragged synthetic (phonemes, prompt codes [t,8], response codes [t,n_levels]) lists."""
+    rng = np.random.Generator(np.random.PCG64(seed + 104729))
+    texts, proms, resps = [], [], []
+    for _ in range(batch):
+        texts.append(torch.from_numpy(rng.integers(1, 70, size=int(rng.integers(*t_text))).astype(np.int64)))
+        proms.append(torch.from_numpy(rng.integers(0, 1024, size=(int(rng.integers(*t_prom)), 8)).astype(np.int64)))
+        resps.append(torch.from_numpy(rng.integers(0, 1024, size=(int(rng.integers(*t_resp)), n_levels)).astype(np.int64)))
+    return texts, proms, resps
