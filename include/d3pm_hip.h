@@ -199,6 +199,46 @@ int d3pm_q_sample(const d3pm_shape *shape, int batch, const int32_t *x0, int32_t
 int d3pm_uniform(uint64_t seed, int t, uint32_t row0, int rows, int n_classes, int stream_id,
                  float *out, void *stream);
 
+/* Stock NAR model: quantizer levels 1..7 given level 0 ----------------------------
+ * Replaces one pass of NAR.forward's inference loop (nar.py:76-101) = Base.forward (base.py:403-499) at
+ * `quant_levels = level`: input assembly [text | sep | prompt | sep | response] + sinusoid, n_layers x
+ * {AdaLN -> masked attention -> residual, AdaLN -> GELU FFN -> residual} (:161-234), classifier, and the
+ * temperature sampling of the response rows (Gumbel-max over Philox stream 2 instead of torch's multinomial). */
+typedef struct d3pm_nar_shape {
+  int32_t d_model, n_heads, n_layers, n_tokens, n_prom_levels, n_resp_levels, dtype;
+} d3pm_nar_shape;
+
+typedef struct d3pm_nar_block_weights {
+  const void *attn_norm_emb;        /* blocks.i.attn.norm.emb.weight [n_resp_levels][2d]  (AdaLN :139) */
+  const void *to_qkv_w;             /* [3d][d], no bias (:100)                                         */
+  const void *to_out_w, *to_out_b;  /* [d][d], [d] (:101)                                              */
+  const void *ffn_norm_emb;         /* blocks.i.ffn.norm.emb.weight                                    */
+  const void *ffn0_w, *ffn0_b;      /* [4d][d], [4d] (:216)                                            */
+  const void *ffn3_w, *ffn3_b;      /* [d][4d], [d]  (:219)                                            */
+} d3pm_nar_block_weights;
+
+typedef struct d3pm_nar_weights {
+  const void *text_emb;             /* [n_tokens][d]                 (:336) */
+  const void *proms_emb;            /* [n_prom_levels][n_tokens][d]  (:339) */
+  const void *resps_emb;            /* [n_resp_levels][n_tokens][d]  (:340) */
+  const void *sep;                  /* [d]                           (:344) */
+  const void *classifier_w, *classifier_b;   /* [n_tokens][d], [n_tokens] (:360) */
+  const void *pe;                   /* [pe_rows][d] sinusoid table in the model dtype (:38-89) */
+  int32_t pe_rows;
+  const d3pm_nar_block_weights *blocks;      /* HOST array of n_layers entries */
+} d3pm_nar_weights;
+
+size_t d3pm_nar_workspace_bytes(const d3pm_nar_shape *shape, int batch, int t_max);
+
+/* lens device int32 [batch][3] = (t_text, t_prompt, t_response); text device int32 [batch][tt_max];
+ * prom device int32 [batch][tp_max][n_prom_levels] (-1 = level absent); resp device int32
+ * [batch][tr_max][n_resp_levels+1], levels 0..level given, level+1 written; t_max >= max(t_text+t_prompt+t_resp+2);
+ * logits_out optional device [batch][t_max][n_tokens] of `dtype` (all rows, before sampling) or NULL. */
+int d3pm_nar_level(const d3pm_nar_shape *shape, const d3pm_nar_weights *w, int batch, int t_max, const int32_t *lens,
+                   const int32_t *text, int tt_max, const int32_t *prom, int tp_max, int32_t *resp, int tr_max,
+                   int level, float temperature, uint64_t seed, uint32_t utt0, uint32_t flags, void *workspace,
+                   size_t workspace_bytes, void *logits_out, void *stream);
+
 /* Single-operator entry points (kernel-level parity tests and micro-benchmarks).  `family`:
  * 0 = auto (MFMA when the shape tiles, else generic), 1 = generic FMA kernels, 2 = MFMA (fails with
  * D3PM_E_SHAPE when unsupported).  Same contracts as inside the denoiser:

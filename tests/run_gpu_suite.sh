@@ -7,6 +7,7 @@ for st in $STAGES; do
   case $st in
     kernels) timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -p no:cacheprovider -x > gpurun_out/pytest_kernels.log 2>&1; rc=$?; tail -15 gpurun_out/pytest_kernels.log;;
     parity)  timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_parity.log 2>&1; rc=$?; tail -25 gpurun_out/pytest_parity.log;;
+    nar)     timeout -k 10 600 python -m pytest tests/test_gpu_nar.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_nar.log 2>&1; rc=$?; tail -25 gpurun_out/pytest_nar.log;;
     smoke)   timeout -k 10 180 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; rc=$?; tail -3 gpurun_out/smoke.log;;
     bench)   timeout -k 10 900 python bench.py --steps 2 --warmup 1 2> gpurun_out/bench.err | tee gpurun_out/bench.json; rc=${PIPESTATUS[0]}; tail -5 gpurun_out/bench.err;;
     noev)    timeout -k 10 600 python bench.py --steps 2 --warmup 1 --no-kernel-events --cpu-steps 0 --no-latency 2> gpurun_out/bench_noev.err | tee gpurun_out/bench_noev.json; rc=${PIPESTATUS[0]};;

@@ -81,12 +81,25 @@ def test_state_dict_layout_is_the_references():
     m.load_state_dict(synth.make_state_dict(synth.D3PMConfig.native()), strict=True)
 
 
+def test_nar_state_dict_layout_is_the_references():
+    from vall_e.vall_e import NAR, synth
+    cfg = synth.NARConfig(d_model=128, n_heads=2, n_layers=2)
+    m = NAR(cfg.n_tokens, cfg.d_model, cfg.n_heads, cfg.n_layers)
+    spec = synth.nar_state_dict_spec(cfg)
+    assert set(m.state_dict()) == set(spec) and all(tuple(m.state_dict()[k].shape) == spec[k] for k in spec)
+    m.load_state_dict(synth.make_nar_state_dict(cfg), strict=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m([torch.tensor([1, 2])], [torch.zeros(3, 8, dtype=torch.long)], [torch.zeros(4, 1, dtype=torch.long)])
+
+
 def test_registry_surface():
     import vall_e.vall_e as vv
     with pytest.raises(ValueError):
         vv.get_model("something")
     with pytest.raises(NotImplementedError):
-        vv.get_model("nar")
+        vv.get_model("ar")                    # the stock causal AR model is out of scope
+    with pytest.raises(NotImplementedError):
+        vv.get_model("nar-bogus")
     from vall_e.vall_e.ar import AR as AR2
     assert AR2 is vv.AR
 

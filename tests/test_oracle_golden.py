@@ -128,3 +128,41 @@ def test_full_loop_trajectory_utt1():
     tr = []
     orc.generate(texts[1], proms[1], O.philox_noise(7, cfg.canvas), trace=tr)
     assert np.array_equal(torch.stack(tr).numpy(), g["traj_utt1_seed7"].astype(np.int64))
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("f16", torch.float16)])
+def test_nar_oracle_matches_reference_fixture(tag, dtype):
+    """Stock NAR (levels 1..7): response-row logits at levels 0 and 3 and the full generation under torch seed 0
+    against what the reference produced (tests/golden/nar_small.npz)."""
+    from oracle import nar_oracle as N
+    from vall_e.vall_e import synth
+    g = load("nar_small.npz")
+    cfg = synth.NARConfig(d_model=128, n_heads=2, n_layers=2)
+    sd = {k: v.to(dtype) for k, v in synth.make_nar_state_dict(cfg, 0).items()}
+    conv = (lambda a: torch.from_numpy(a)) if dtype == torch.float32 else f16
+    exact = same_platform_as_golden()
+    for lvl, n_lv in ((0, 1), (3, 4)):
+        texts, proms, resps = synth.make_nar_inputs(2, 1, n_levels=n_lv)
+        with torch.no_grad():
+            lg = N.level_logits(sd, cfg.n_heads, cfg.n_layers, texts, proms, resps, lvl)
+        for b in range(2):
+            mine, ref = torch.cat([lg[b][:8], lg[b][-8:]]), conv(g[f"logits_l{lvl}_utt{b}_{tag}"])
+            if exact:
+                assert torch.equal(mine, ref), (lvl, b)
+            else:
+                assert (mine.float() - ref.float()).abs().max() < (1e-4 if dtype == torch.float32 else 2e-2)
+    if exact:
+        texts, proms, resps = synth.make_nar_inputs(2, 1)
+        torch.manual_seed(0)
+        y = N.generate(sd, cfg.n_heads, cfg.n_layers, texts, proms, resps, 0.2, sampler="torch")
+        for b in range(2):
+            assert np.array_equal(y[b].numpy(), g[f"generated_seed0_utt{b}_{tag}"].astype(np.int64))
+
+
+def test_gumbel_max_is_the_categorical_distribution():
+    """The build samples NAR levels with a Philox Gumbel-max instead of torch's multinomial: same distribution."""
+    from oracle import nar_oracle as N
+    logits = torch.tensor([[2.0, 0.5, -1.0, 0.0, 1.0]]).repeat(20000, 1)
+    ids = N.sample_gumbel([logits], 1.0, seed=5, level=0)[0]
+    freq = torch.bincount(ids, minlength=5).float() / len(ids)
+    assert (freq - torch.softmax(logits[0], -1)).abs().max() < 0.012

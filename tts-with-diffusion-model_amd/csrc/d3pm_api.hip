@@ -446,6 +446,97 @@ int d3pm_uniform(uint64_t seed, int t, uint32_t row0, int rows, int n_classes, i
   return uniform_launch(seed, t, row0, rows, n_classes, stream_id, out, static_cast<hipStream_t>(stream));
 }
 
+// ---- stock NAR model -------------------------------------------------------------------------------------
+struct NarWs { char *x, *h, *qkv, *att, *ffn, *logits; uint8_t* mask; int32_t* key_len; size_t total; };
+static NarWs carve_nar(const d3pm_nar_shape& sh, int batch, int t_max, char* base) {
+  const size_t es = dtype_size(sh.dtype), n = static_cast<size_t>(batch) * t_max, d = sh.d_model;
+  NarWs w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+  w.x = take(n * d * es);
+  w.h = take(n * d * es);
+  w.qkv = take(n * 3 * d * es);
+  w.att = take(n * d * es);
+  w.ffn = take(n * 4 * d * es);
+  w.logits = take(n * sh.n_tokens * es);
+  w.mask = reinterpret_cast<uint8_t*>(take(n));
+  w.key_len = reinterpret_cast<int32_t*>(take(static_cast<size_t>(batch) * 4));
+  w.total = off;
+  return w;
+}
+static int check_nar(const d3pm_nar_shape* sh, int batch, int t_max) {
+  D3PM_REQUIRE(sh && batch > 0 && t_max > 0 && sh->d_model > 0 && sh->n_heads > 0 && sh->d_model % sh->n_heads == 0 &&
+                   sh->n_layers > 0 && sh->n_tokens > 1 && sh->n_prom_levels > 0 && sh->n_resp_levels > 0,
+               D3PM_E_ARG, "inconsistent d3pm_nar_shape");
+  D3PM_REQUIRE(sh->dtype == D3PM_F32 || sh->dtype == D3PM_F16 || sh->dtype == D3PM_BF16, D3PM_E_ARG, "bad dtype %d", sh->dtype);
+  return D3PM_OK;
+}
+
+size_t d3pm_nar_workspace_bytes(const d3pm_nar_shape* sh, int batch, int t_max) {
+  if (check_nar(sh, batch, t_max) != D3PM_OK) return 0;
+  return carve_nar(*sh, batch, t_max, nullptr).total;
+}
+
+int d3pm_nar_level(const d3pm_nar_shape* sh, const d3pm_nar_weights* w, int batch, int t_max, const int32_t* lens,
+                   const int32_t* text, int tt_max, const int32_t* prom, int tp_max, int32_t* resp, int tr_max, int level,
+                   float temperature, uint64_t seed, uint32_t utt0, uint32_t flags, void* workspace, size_t workspace_bytes,
+                   void* logits_out, void* stream) {
+  D3PM_TRY(check_nar(sh, batch, t_max));
+  D3PM_REQUIRE(w && w->blocks && w->text_emb && w->proms_emb && w->resps_emb && w->sep && w->classifier_w && w->classifier_b &&
+                   w->pe && lens && text && prom && resp && workspace,
+               D3PM_E_ARG, "d3pm_nar_level: null pointer");
+  D3PM_REQUIRE(level >= 0 && level < sh->n_resp_levels && temperature > 0.f && w->pe_rows >= t_max && tt_max > 0 && tp_max > 0 &&
+                   tr_max > 0 && t_max >= tt_max + tp_max + tr_max + 2,
+               D3PM_E_ARG, "d3pm_nar_level: bad level / temperature / sizes");
+  NarWs ws = carve_nar(*sh, batch, t_max, static_cast<char*>(workspace));
+  D3PM_REQUIRE(workspace_bytes >= ws.total, D3PM_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int dt = sh->dtype, d = sh->d_model, n = batch * t_max, hd = d / sh->n_heads, stride = sh->n_resp_levels + 1;
+  const size_t es = dtype_size(dt);
+
+  NarEmbedArgs e;
+  e.lens = lens; e.text = text; e.tt_max = tt_max; e.prom = prom; e.tp_max = tp_max; e.n_prom_levels = sh->n_prom_levels;
+  e.resp = resp; e.tr_max = tr_max; e.resp_stride = stride; e.n_given = level + 1;
+  e.w_text = w->text_emb; e.w_prom = w->proms_emb; e.w_resp = w->resps_emb; e.sep = w->sep; e.pe = w->pe;
+  e.x = ws.x; e.row_mask = ws.mask; e.key_len = ws.key_len; e.batch = batch; e.t_max = t_max; e.d = d; e.n_tokens = sh->n_tokens;
+  D3PM_TRY(nar_embed(dt, e, s));
+
+  for (int l = 0; l < sh->n_layers; ++l) {
+    const d3pm_nar_block_weights& b = w->blocks[l];
+    // x = (x + to_out(attention(AdaLN(x) * m)) * m) * m
+    D3PM_TRY(adaln(dt, ws.x, ws.h, at(b.attn_norm_emb, static_cast<size_t>(level) * 2 * d, es), ws.mask, n, d, s));
+    LinearArgs g;
+    g.X = ws.h; g.ldx = d; g.W = b.to_qkv_w; g.Y = ws.qkv; g.ldy = 3 * d; g.M = n; g.N = 3 * d; g.K = d;
+    D3PM_TRY(run_linear(dt, g, flags, s));
+    AttnArgs a;
+    a.Q = ws.qkv; a.ldq = 3 * d; a.K = at(ws.qkv, d, es); a.V = at(ws.qkv, 2 * d, es); a.ldkv = 3 * d; a.O = ws.att; a.ldo = d;
+    a.B = batch; a.Tq = t_max; a.S = t_max; a.H = sh->n_heads; a.hd = hd; a.scale = 1.0f / std::sqrt(static_cast<float>(hd));
+    a.key_len = ws.key_len;
+    D3PM_TRY(run_attention(dt, a, flags, s));
+    g = LinearArgs();
+    g.X = ws.att; g.ldx = d; g.W = b.to_out_w; g.bias = b.to_out_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
+    g.row_mask = ws.mask; g.mask_period = n; g.M = n; g.N = d; g.K = d;
+    D3PM_TRY(run_linear(dt, g, flags, s));
+    // x = (x + ffn(AdaLN(x) * m)) * m
+    D3PM_TRY(adaln(dt, ws.x, ws.h, at(b.ffn_norm_emb, static_cast<size_t>(level) * 2 * d, es), ws.mask, n, d, s));
+    g = LinearArgs();
+    g.X = ws.h; g.ldx = d; g.W = b.ffn0_w; g.bias = b.ffn0_b; g.Y = ws.ffn; g.ldy = 4 * d; g.M = n; g.N = 4 * d; g.K = d; g.act = ACT_GELU;
+    D3PM_TRY(run_linear(dt, g, flags, s));
+    g = LinearArgs();
+    g.X = ws.ffn; g.ldx = 4 * d; g.W = b.ffn3_w; g.bias = b.ffn3_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
+    g.row_mask = ws.mask; g.mask_period = n; g.M = n; g.N = d; g.K = 4 * d;
+    D3PM_TRY(run_linear(dt, g, flags, s));
+  }
+  LinearArgs g;
+  g.X = ws.x; g.ldx = d; g.W = w->classifier_w; g.bias = w->classifier_b; g.Y = ws.logits; g.ldy = sh->n_tokens; g.M = n;
+  g.N = sh->n_tokens; g.K = d;
+  D3PM_TRY(run_linear(dt, g, flags, s));
+  if (logits_out)
+    D3PM_CHECK_HIP(hipMemcpyAsync(logits_out, ws.logits, static_cast<size_t>(n) * sh->n_tokens * es, hipMemcpyDeviceToDevice, s));
+  return nar_sample(dt, ws.logits, sh->n_tokens, lens, resp, tr_max, stride, t_max, sh->n_tokens, level, temperature, seed, utt0,
+                    (flags & D3PM_FLAG_GREEDY) ? 1 : 0, batch, s);
+}
+
 int d3pm_op_linear(int dtype, int family, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy,
                    const void* R1, const void* R2, int ldr, const uint8_t* row_mask, int mask_period, int M, int N, int K,
                    int act, void* stream) {

@@ -136,17 +136,19 @@ template <typename T>
 __global__ __launch_bounds__(256) void attention_rows(const T* __restrict__ Q, int ldq,
                                                       const T* __restrict__ Kp,
                                                       const T* __restrict__ Vp, int ldkv,
-                                                      T* __restrict__ O, int ldo, int Tq, int S,
-                                                      int hd, float scale, int q_per_wave) {
+                                                      T* __restrict__ O, int ldo, int Tq, int S_pad,
+                                                      int hd, float scale, int q_per_wave,
+                                                      const int32_t* __restrict__ key_len) {
   extern __shared__ float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  float* sc = smem + static_cast<size_t>(wave) * (S + hd);
-  float* qs = sc + S;
+  float* sc = smem + static_cast<size_t>(wave) * (S_pad + hd);
+  float* qs = sc + S_pad;
   const int b = blockIdx.z, h = blockIdx.y;
+  const int S = key_len ? min(key_len[b], S_pad) : S_pad;     // valid keys of this utterance
   const int hdp = hd < kWave ? hd : kWave;       // columns handled per pass
   const int G = kWave / hdp;                      // key groups per pass
-  const T* Kb = Kp + static_cast<size_t>(b) * S * ldkv + h * hd;
-  const T* Vb = Vp + static_cast<size_t>(b) * S * ldkv + h * hd;
+  const T* Kb = Kp + static_cast<size_t>(b) * S_pad * ldkv + h * hd;
+  const T* Vb = Vp + static_cast<size_t>(b) * S_pad * ldkv + h * hd;
   for (int qi = 0; qi < q_per_wave; ++qi) {
     const int i = (blockIdx.x * nw + wave) * q_per_wave + qi;
     const bool active = i < Tq;                    // wave-uniform; barriers stay block-uniform
@@ -305,7 +307,7 @@ int generic_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     D3PM_REQUIRE(lds <= 64 * 1024, D3PM_E_SHAPE, "generic attention: %d keys exceed the LDS budget", a.S);
     attention_rows<T><<<grid, nw * kWave, lds, s>>>(static_cast<const T*>(a.Q), a.ldq, static_cast<const T*>(a.K),
                                                    static_cast<const T*>(a.V), a.ldkv, static_cast<T*>(a.O),
-                                                   a.ldo, a.Tq, a.S, a.hd, a.scale, qpw);
+                                                   a.ldo, a.Tq, a.S, a.hd, a.scale, qpw, a.key_len);
     D3PM_LAUNCH_CHECK();
     return D3PM_OK;
   });

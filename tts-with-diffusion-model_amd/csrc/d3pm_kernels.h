@@ -34,6 +34,9 @@ struct AttnArgs {
   void* O = nullptr; int ldo = 0;
   int B = 0, Tq = 0, S = 0, H = 0, hd = 0;
   float scale = 1.f;
+  // optional per-utterance number of valid keys (device int32[B]): keys >= key_len[b] are masked out
+  // (the key-padding mask of the stock NAR attention, base.py:118-124); S is then the padded key count
+  const int32_t* key_len = nullptr;
   // optional second, independent problem with the same B / Tq / H / hd launched in the same grid
   // (the text and prompt cross-attentions of one DiT block): its own Q, K/V (S2 keys) and output
   const void* Q2 = nullptr; const void* K2 = nullptr; const void* V2 = nullptr; void* O2 = nullptr; int S2 = 0;
@@ -94,5 +97,21 @@ bool fast_layernorm_supported(int dtype, const LayerNormArgs& a);
 int fast_layernorm(int dtype, const LayerNormArgs& a, hipStream_t s);
 
 PosteriorConsts make_posterior_consts(const d3pm_schedule* sched, int t);
+
+// ---- stock NAR model (levels 1..7): input assembly, AdaLN, temperature sampling (d3pm_nar.hip) ----
+struct NarEmbedArgs {
+  const int32_t* lens = nullptr;                 // [B][3] = (t_text, t_prompt, t_response)
+  const int32_t* text = nullptr; int tt_max = 0;  // [B][tt_max]
+  const int32_t* prom = nullptr; int tp_max = 0; int n_prom_levels = 8;   // [B][tp_max][n_prom_levels], -1 = level absent
+  const int32_t* resp = nullptr; int tr_max = 0; int resp_stride = 8; int n_given = 1;   // [B][tr_max][resp_stride]
+  const void *w_text = nullptr, *w_prom = nullptr, *w_resp = nullptr, *sep = nullptr, *pe = nullptr;
+  void* x = nullptr; uint8_t* row_mask = nullptr; int32_t* key_len = nullptr;
+  int batch = 0, t_max = 0, d = 0, n_tokens = 0;
+};
+int nar_embed(int dtype, const NarEmbedArgs& a, hipStream_t s);
+int adaln(int dtype, const void* x, void* y, const void* emb_row, const uint8_t* row_mask, int M, int d, hipStream_t s);
+int nar_sample(int dtype, const void* logits, int ldl, const int32_t* lens, int32_t* resp, int tr_max, int resp_stride,
+               int t_max, int n_tokens, int level, float temperature, uint64_t seed, uint32_t utt0, int greedy, int batch,
+               hipStream_t s);
 
 }  // namespace d3pm

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
                                                       const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo,
                                                       int Tq, int S, float scale, int H, int n_qblocks,
                                                       const T* __restrict__ Q2, const T* __restrict__ K2,
-                                                      const T* __restrict__ V2, T* __restrict__ O2, int S2, int n_first) {
+                                                      const T* __restrict__ V2, T* __restrict__ O2, int S2, int n_first,
+                                                      const int32_t* __restrict__ key_len) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE];   // [buffer][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
@@ -75,10 +76,12 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
     Q = Q2; Kp = K2; Vp = V2; O = O2; S = S2;
   }
   const int qb = bid % n_qblocks, h = (bid / n_qblocks) % H, b = bid / (n_qblocks * H);
+  const int S_pad = S;                                 // row stride of the K/V batches
+  if (key_len) S = min(key_len[b], S_pad);             // valid keys of this utterance (>= 1)
   const int q0 = (qb * 4 + wave) * (16 * QG);
   const int qi = lane & 15, g = lane >> 4;
-  const T* Kb = Kp + static_cast<size_t>(b) * S * ldkv + h * HD;
-  const T* Vb = Vp + static_cast<size_t>(b) * S * ldkv + h * HD;
+  const T* Kb = Kp + static_cast<size_t>(b) * S_pad * ldkv + h * HD;
+  const T* Vb = Vp + static_cast<size_t>(b) * S_pad * ldkv + h * HD;
 
   // Q fragments (B operand of S^T = K.Q^T): lane holds q[query][32*ks + 8g .. +7], pre-scaled by
   // sqrt(1/hd) * log2(e) so that the scores come out of the MFMA in the log2 domain (softmax via v_exp_f32)
@@ -265,7 +268,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
                                                static_cast<const T*>(a.V), a.ldkv, static_cast<T*>(a.O), a.ldo, a.Tq, \
                                                a.S, a.scale, a.H, n_qblocks, static_cast<const T*>(a.Q2),                 \
                                                static_cast<const T*>(a.K2), static_cast<const T*>(a.V2),                 \
-                                               static_cast<T*>(a.O2), a.S2, n_first)
+                                               static_cast<T*>(a.O2), a.S2, n_first, a.key_len)
   if (dtype == D3PM_F16) { if (qg == 1) D3PM_ATTN(f16, 1); else D3PM_ATTN(f16, 2); }
   else { if (qg == 1) D3PM_ATTN(bf16, 1); else D3PM_ATTN(bf16, 2); }
 #undef D3PM_ATTN

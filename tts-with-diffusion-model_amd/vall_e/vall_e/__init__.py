@@ -1,12 +1,12 @@
 """Model registry with the reference's surface (/root/reference/vall_e/vall_e/__init__.py:7-59).
 
-Only the discrete-diffusion sampler is implemented by this package (the stock AR / NAR VALL-E
-models are out of its scope); their names raise NotImplementedError instead of
-silently building something else.  Importing this package has no argv side effect (the reference's
+This package implements the discrete-diffusion sampler ("diffusion*") and the stock NAR model that completes its
+output ("nar*"); the stock causal AR model is out of scope and raises NotImplementedError.  Importing this package has no argv side effect (the reference's
 `from ..config import cfg` parses sys.argv at import, config.py:96).
 """
 from .ar_discrete import AR
-from .synth import D3PMConfig
+from .nar import NAR
+from .synth import D3PMConfig, NARConfig
 
 
 def get_model(name: str):
@@ -16,9 +16,18 @@ def get_model(name: str):
     if name.startswith("diffusion"):
         max_n_levels, n_tokens, d_model, n_steps, n_heads, num_layers = 8, 1024, 512, 100, 8, 6
         return AR(d_model, n_steps, n_tokens, max_n_levels, n_heads, num_layers).to("cuda")
-    if name.startswith("ar") or name.startswith("nar"):
-        raise NotImplementedError(f"{name}: the stock VALL-E AR/NAR models are not part of the D3PM sampler build")
+    if name.startswith("nar"):
+        # the reference sizes (__init__.py:34-57): -quarter 256/4/12, -half 512/8/12, default 1024/16/12; 1024 tokens
+        if "-quarter" in name:
+            return NAR(1024, d_model=256, n_heads=4, n_layers=12).to("cuda")
+        if "-half" in name:
+            return NAR(1024, d_model=512, n_heads=8, n_layers=12).to("cuda")
+        if name != "nar":
+            raise NotImplementedError(name)
+        return NAR(1024, d_model=1024, n_heads=16, n_layers=12).to("cuda")
+    if name.startswith("ar"):
+        raise NotImplementedError(f"{name}: the stock causal VALL-E AR model is not part of this build")
     raise ValueError("Model name should start with AR or NAR.")
 
 
-__all__ = ["AR", "D3PMConfig", "get_model"]
+__all__ = ["AR", "NAR", "D3PMConfig", "NARConfig", "get_model"]

@@ -60,6 +60,25 @@ class CondWeights(C.Structure):
                 ("prompt_encoder", EncoderWeights)]
 
 
+class NarShape(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("d_model", "n_heads", "n_layers", "n_tokens", "n_prom_levels", "n_resp_levels",
+                                         "dtype")]
+
+
+_NAR_BLOCK_FIELDS = ("attn_norm_emb", "to_qkv_w", "to_out_w", "to_out_b", "ffn_norm_emb", "ffn0_w", "ffn0_b", "ffn3_w",
+                     "ffn3_b")
+
+
+class NarBlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _NAR_BLOCK_FIELDS]
+
+
+class NarWeights(C.Structure):
+    _fields_ = [("text_emb", C.c_void_p), ("proms_emb", C.c_void_p), ("resps_emb", C.c_void_p), ("sep", C.c_void_p),
+                ("classifier_w", C.c_void_p), ("classifier_b", C.c_void_p), ("pe", C.c_void_p), ("pe_rows", C.c_int32),
+                ("blocks", C.POINTER(NarBlockWeights))]
+
+
 class ScheduleC(C.Structure):
     _fields_ = [("timesteps", C.c_int32), ("d", C.POINTER(C.c_uint16)), ("c", C.POINTER(C.c_uint16)),
                 ("dbar", C.POINTER(C.c_uint16)), ("cbar", C.POINTER(C.c_uint16))]
@@ -90,6 +109,10 @@ SIGNATURES = {
     "d3pm_q_sample": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_void_p]),
     "d3pm_uniform": (C.c_int, [C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "d3pm_nar_workspace_bytes": (C.c_size_t, [C.POINTER(NarShape), C.c_int, C.c_int]),
+    "d3pm_nar_level": (C.c_int, [C.POINTER(NarShape), C.POINTER(NarWeights), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64,
+                                 C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "d3pm_op_linear": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_void_p]),
@@ -352,6 +375,49 @@ def op_layernorm(x, w, b, film=None, eps=1e-6):
     check(lib().d3pm_op_layernorm(dtype_code(x.dtype), _p(x), _p(y), _p(w), _p(b), _p(film), x.shape[0], x.shape[1],
                                   eps, stream_ptr()), "d3pm_op_layernorm")
     return y
+
+
+class NarRunner:
+    """Pointer tables + workspace of the stock NAR model (d3pm_nar_level)."""
+
+    def __init__(self, cfg, tensors: dict, dtype: torch.dtype, device, pe: torch.Tensor):
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.shape = NarShape(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.n_tokens, cfg.n_prom_levels, cfg.n_resp_levels,
+                              dtype_code(dtype))
+        self._keep = [pe]
+
+        def ptr(key):
+            t = tensors[key]
+            if not (t.is_cuda and t.is_contiguous()):
+                raise D3PMError(f"weight {key} must be a contiguous device tensor")
+            self._keep.append(t)
+            return t.data_ptr()
+
+        self.blocks = (NarBlockWeights * cfg.n_layers)()
+        names = {"attn_norm_emb": "attn.norm.emb.weight", "to_qkv_w": "attn.block.to_qkv.weight",
+                 "to_out_w": "attn.block.to_out.weight", "to_out_b": "attn.block.to_out.bias",
+                 "ffn_norm_emb": "ffn.norm.emb.weight", "ffn0_w": "ffn.block.0.weight", "ffn0_b": "ffn.block.0.bias",
+                 "ffn3_w": "ffn.block.3.weight", "ffn3_b": "ffn.block.3.bias"}
+        for i in range(cfg.n_layers):
+            for field, key in names.items():
+                setattr(self.blocks[i], field, ptr(f"blocks.{i}.{key}"))
+        self.weights = NarWeights(ptr("text_emb.weight"), ptr("proms_emb.weight"), ptr("resps_emb.weight"), ptr("sep"),
+                                  ptr("classifier.weight"), ptr("classifier.bias"), pe.data_ptr(), pe.shape[0], self.blocks)
+        self._ws = None
+
+    def level(self, lens, text, prom, resp, t_max, level, temperature, seed, utt0=0, flags=0, want_logits=False):
+        """One quantizer level for the whole batch; `resp` [B, tr_max, n_resp_levels+1] int32 is updated in place."""
+        cfg, B = self.cfg, lens.shape[0]
+        need = lib().d3pm_nar_workspace_bytes(C.byref(self.shape), B, t_max)
+        if need == 0:
+            raise D3PMError("d3pm_nar_workspace_bytes: " + lib().d3pm_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        logits = torch.empty((B, t_max, cfg.n_tokens), dtype=self.dtype, device=self.device) if want_logits else None
+        check(lib().d3pm_nar_level(C.byref(self.shape), C.byref(self.weights), B, t_max, _p(lens), _p(text), text.shape[1],
+                                   _p(prom), prom.shape[1], _p(resp), resp.shape[1], int(level), float(temperature), seed,
+                                   utt0, flags, _p(self._ws), self._ws.numel(), _p(logits), stream_ptr()), "d3pm_nar_level")
+        return logits
 
 
 def uniform(seed: int, t: int, row0: int, rows: int, n_classes: int, stream_id: int, device) -> torch.Tensor:
