@@ -486,7 +486,7 @@ int d3pm_nar_level(const d3pm_nar_shape* sh, const d3pm_nar_weights* w, int batc
                    w->pe && lens && text && prom && resp && workspace,
                D3PM_E_ARG, "d3pm_nar_level: null pointer");
   D3PM_REQUIRE(level >= 0 && level < sh->n_resp_levels && temperature > 0.f && w->pe_rows >= t_max && tt_max > 0 && tp_max > 0 &&
-                   tr_max > 0 && t_max >= tt_max + tp_max + tr_max + 2,
+                   tr_max > 0,
                D3PM_E_ARG, "d3pm_nar_level: bad level / temperature / sizes");
   NarWs ws = carve_nar(*sh, batch, t_max, static_cast<char*>(workspace));
   D3PM_REQUIRE(workspace_bytes >= ws.total, D3PM_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);

@@ -105,7 +105,7 @@ __global__ void nar_sample_rows(const T* __restrict__ logits, int ldl, const int
   if (idx >= batch * tr_max) return;
   const int b = idx / tr_max, f = idx % tr_max;
   const int tt = lens[b * 3], tp = lens[b * 3 + 1], tr = lens[b * 3 + 2];
-  if (f >= tr) return;
+  if (f >= tr || tt + tp + 2 + f >= t_max) return;   // a sequence longer than the padded grid is truncated, never read past
   const T* lr = logits + (static_cast<size_t>(b) * t_max + (tt + tp + 2 + f)) * ldl;
   const int groups = (n_tokens + 3) >> 2;
   int best_j = 0;
