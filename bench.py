@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-steps", type=int, default=4, help="diffusion iterations timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-nar", action="store_true", help="skip the extra NAR (levels 1..7) measurement")
     ap.add_argument("--streams", type=int, default=1, help="independent batch chunks on separate HIP streams")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket GEMM launches with HIP events (roofline.achieved is then 0): measures what the "
@@ -85,6 +86,32 @@ def pmc_traffic(kernel_class="gemm"):
         return data[kernel_class]["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def nar_stage(dev, dtype, batch, cfg, level0):
+    """The step right after the D3PM path (reference __main__.py:36-38): the stock NAR model (registry size
+    d=1024 / 16 heads / 12 layers) fills quantizer levels 1..7 for the same batch.  Reported beside, never inside,
+    `value` (the BASELINE.json metric counts the D3PM stage)."""
+    from vall_e.vall_e import NAR, synth
+    ncfg = synth.NARConfig()
+    nar = NAR(ncfg.n_tokens, ncfg.d_model, ncfg.n_heads, ncfg.n_layers)
+    nar.load_state_dict(synth.make_nar_state_dict(ncfg, 0))
+    nar = nar.to(dtype).to(dev)
+    texts, proms = synth.make_inputs(cfg, batch, 1)
+    resps = [level0[b, : cfg.n_frames].clamp(max=ncfg.n_tokens - 1).reshape(-1, 1).cpu() for b in range(batch)]
+    nar(texts, proms, resps, seed=1)                       # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 2
+    for i in range(reps):
+        full = nar(texts, proms, resps, seed=2 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert full[0].shape == (cfg.n_frames, 8)
+    rows = sum(len(t) + len(p) + len(r) + 2 for t, p, r in zip(texts, proms, resps))
+    flops = 7.0 * rows * ncfg.n_layers * 24 * ncfg.d_model ** 2       # GEMM flops only (QKV, out, FFN), 7 levels
+    return {"model": f"NAR d={ncfg.d_model} H={ncfg.n_heads} L={ncfg.n_layers}", "seconds_per_batch": dt,
+            "codec_tokens_per_s": 7 * batch * cfg.n_frames / dt, "gemm_tflops": flops / dt / 1e12}
 
 
 def cpu_baseline(cfg, sd32, texts, proms, n_iters):
@@ -215,6 +242,11 @@ def main():
                 torch.cuda.synchronize()
                 lat.append((time.perf_counter() - t1) * 1e3)
             result["p50_utterance_latency_ms"] = statistics.median(lat[1:])
+        if not args.no_nar and args.config == "libritts":
+            result["nar_levels_1to7"] = nar_stage(dev, dtype, batch, cfg, out[:batch])
+            d3pm_s = ms_per_step * 1e-3
+            result["nar_levels_1to7"]["all_8_levels_codec_tokens_per_s"] = (
+                8 * batch * cfg.n_frames / (d3pm_s + result["nar_levels_1to7"]["seconds_per_batch"]))
         if world == 1 and args.cpu_steps > 0:
             note("timing the CPU port of the reference sampler")
             cpu_texts, cpu_proms = synth.make_inputs(cfg, 1, 1)
