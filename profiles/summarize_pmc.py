@@ -16,7 +16,8 @@ CLASSES = {"gemm": "gemm_mfma", "attention": "attn_mfma", "layernorm": "layernor
 
 
 def load(directory, counter):
-    path = glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True)[0]
+    import os
+    path = max(glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:

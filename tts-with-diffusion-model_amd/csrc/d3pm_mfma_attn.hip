@@ -49,9 +49,11 @@ template <> __device__ __forceinline__ floatx4 mma<bf16>(uint4 a, uint4 b, float
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * ROWB + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
 
+// two floats -> one packed 16-bit pair; the vector conversion lowers to a single v_cvt_pk_{bf16,f16}_f32
 template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
-  T x = static_cast<T>(a), y = static_cast<T>(b);
-  return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, x)) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, y)) << 16);
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  typedef T pair __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2v){a, b}, pair));
 }
 
 template <typename T, int QG>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
@@ -131,12 +133,14 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
   store_tile(smem, st);
   __syncthreads();
 
-  float m_run[QG], l_part[QG];
-  floatx4 acc_o[QG][4];
+  float m_run[QG];
+  floatx4 acc_o[QG][4], acc_l[QG];
+  const uint32_t one2 = pack2<T>(1.0f, 1.0f);
+  const uint4 ones = uint4{one2, one2, one2, one2};
 #pragma unroll
   for (int qg = 0; qg < QG; ++qg) {
     m_run[qg] = -INFINITY;
-    l_part[qg] = 0.f;
+    acc_l[qg] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc_o[qg][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
   }
@@ -173,26 +177,25 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[qg][kt][r] = (key_base + kt * 16 + r < S) ? s[qg][kt][r] : -INFINITY;
       }
-      float mx = fmaxf(fmaxf(s[qg][0][0], s[qg][0][1]), fmaxf(s[qg][0][2], s[qg][0][3]));
+      float mx = fmaxf(s[qg][0][0], s[qg][0][1]);          // linear chain: hipcc folds pairs into v_max3_f32
+      mx = fmaxf(fmaxf(mx, s[qg][0][2]), s[qg][0][3]);
 #pragma unroll
-      for (int kt = 1; kt < 4; ++kt)
-        mx = fmaxf(mx, fmaxf(fmaxf(s[qg][kt][0], s[qg][kt][1]), fmaxf(s[qg][kt][2], s[qg][kt][3])));
+      for (int kt = 1; kt < 4; ++kt) {
+        mx = fmaxf(fmaxf(mx, s[qg][kt][0]), s[qg][kt][1]);
+        mx = fmaxf(fmaxf(mx, s[qg][kt][2]), s[qg][kt][3]);
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
       mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
       const float m_new = fmaxf(m_run[qg], mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);      // exp2(-inf) = 0 on the first tile
       m_run[qg] = m_new;
-      float psum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[qg][kt][r] - m_new);
-          s[qg][kt][r] = p;
-          psum += p;
-        }
-      l_part[qg] = l_part[qg] * alpha + psum;
+        for (int r = 0; r < 4; ++r) s[qg][kt][r] = __builtin_amdgcn_exp2f(s[qg][kt][r] - m_new);
       if (!__all(alpha == 1.0f)) {                       // the running max moved for some query of this wave
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc_l[qg][r] *= alpha;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -222,15 +225,19 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) acc_o[qg][dt] = mma<T>(vf, pf[qg][kb2], acc_o[qg][dt]);
       }
+    // row sums on the matrix pipe: ones^T . P^T adds the (rounded) probabilities of all 64 keys of the tile for
+    // the lane's query into every register of acc_l -- 2 MFMAs instead of 16 v_add + the final shuffles
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+      for (int qg = 0; qg < QG; ++qg) acc_l[qg] = mma<T>(ones, pf[qg][kb2], acc_l[qg]);
     if (more) store_tile(smem + ((tile + 1) & 1) * 2 * TILE, st);
     __syncthreads();
   }
 
 #pragma unroll
   for (int qg = 0; qg < QG; ++qg) {
-    float l = l_part[qg] + __shfl_xor(l_part[qg], 16, kWave);
-    l += __shfl_xor(l, 32, kWave);
-    const float inv = 1.0f / l;
+    const float inv = 1.0f / acc_l[qg][0];
     const int qrow = q0 + qg * 16 + qi;
     if (qrow < Tq) {
       T* op = O + (static_cast<size_t>(b) * Tq + qrow) * ldo + h * HD;
