@@ -44,8 +44,7 @@ enum {
 /* flags for d3pm_sample_loop / d3pm_denoise_step */
 enum {
   D3PM_FLAG_GREEDY = 1,        /* argmax of the posterior without Gumbel noise   */
-  D3PM_FLAG_FORCE_GENERIC = 2, /* never take the MFMA kernels (cross-check / debugging)          */
-  D3PM_FLAG_UNFUSED_SAMPLE = 4 /* materialise [B,T,K] logits and sample in a second kernel       */
+  D3PM_FLAG_FORCE_GENERIC = 2  /* never take the MFMA kernels (cross-check / debugging)          */
 };
 
 typedef struct d3pm_shape {

@@ -416,3 +416,21 @@ def test_vctk_long_prompt_config_runs():
     la, _ = smp.denoise(x, fm, 150, kv_t, kv_p)
     lg, _ = smp.denoise(x, fm, 150, kv_t, kv_p, flags=_hip.FLAG_FORCE_GENERIC)
     assert (la.float() - lg.float()).abs().max().item() < 0.15
+
+
+def test_sample_loop_is_hip_graph_capturable(n16):
+    """include/d3pm_hip.h promises that nothing in the library allocates or synchronises: the whole reverse process
+    can be captured into a HIP graph on a side stream and replayed."""
+    x_eager, fm = n16.model.canvas_init(1)
+    n16.smp.sample_loop(x_eager, fm, 8, 0, n16.kv_t, n16.kv_p, seed=21)
+    x_graph, _ = n16.model.canvas_init(1)
+    x0 = x_graph.clone()
+    n16.smp.workspace(1)                        # allocate outside the capture
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        n16.smp.sample_loop(x_graph, fm, 8, 0, n16.kv_t, n16.kv_p, seed=21)
+    for _ in range(2):
+        x_graph.copy_(x0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(x_graph, x_eager)

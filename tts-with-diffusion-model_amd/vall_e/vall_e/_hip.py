@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 F32, F16, BF16 = 0, 1, 2
-FLAG_GREEDY, FLAG_FORCE_GENERIC, FLAG_UNFUSED_SAMPLE = 1, 2, 4
+FLAG_GREEDY, FLAG_FORCE_GENERIC = 1, 2
 K_GEMM, K_ATTN, K_SAMPLE, K_LN = 0, 1, 2, 3
 
 _DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
