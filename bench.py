@@ -254,6 +254,7 @@ def main():
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result), flush=True)
     if world > 1:
+        torch.distributed.barrier()          # rank 0 may still be timing its extras: leave together
         torch.distributed.destroy_process_group()
 
 
