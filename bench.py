@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-steps", type=int, default=4, help="diffusion iterations timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N>1 path with several ranks sharing one GPU (NCCL refuses that)")
     ap.add_argument("--no-nar", action="store_true", help="skip the extra NAR (levels 1..7) measurement")
     ap.add_argument("--streams", type=int, default=1, help="independent batch chunks on separate HIP streams")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -147,10 +149,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 

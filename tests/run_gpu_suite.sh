@@ -12,6 +12,7 @@ for st in $STAGES; do
     bench)   timeout -k 10 900 python bench.py --steps 2 --warmup 1 2> gpurun_out/bench.err | tee gpurun_out/bench.json; rc=${PIPESTATUS[0]}; tail -5 gpurun_out/bench.err;;
     noev)    timeout -k 10 600 python bench.py --steps 2 --warmup 1 --no-kernel-events --cpu-steps 0 --no-latency 2> gpurun_out/bench_noev.err | tee gpurun_out/bench_noev.json; rc=${PIPESTATUS[0]};;
     streams) rc=0; for k in 1 2 4; do timeout -k 10 300 python bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-latency --streams $k 2>> gpurun_out/bench_streams.err | tee -a gpurun_out/bench_streams.json || rc=$?; done;;
+    dp2)     timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 1 --warmup 1 --backend gloo --batch 4 --profile-iters 3 --cpu-steps 0 --no-latency --no-nar 2> gpurun_out/bench_dp2.err | tee gpurun_out/bench_dp2.json; rc=${PIPESTATUS[0]}; tail -3 gpurun_out/bench_dp2.err;;
     micro)   timeout -k 10 600 python tests/bench_kernels.py > gpurun_out/kernels.txt 2> gpurun_out/kernels.err; rc=$?; cat gpurun_out/kernels.txt;;
     pmc)     cd /tmp && export TMPDIR=/tmp; rc=0
              for c in FETCH_SIZE WRITE_SIZE; do
