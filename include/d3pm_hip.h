@@ -256,7 +256,9 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
 /* Tuning knobs (process-wide; defaults are what bench.py measures).
  * D3PM_TUNE_GEMM_VARIANT: 0 = auto (default): latency schedule for M <= 1536 rows, throughput schedule otherwise;
  *                         2 = always the throughput schedule (one LDS stage, 4 workgroups per CU);
- *                         3 = always the latency schedule (two stages, asm DMA prefetch).  Results are bit-identical.
+ *                         3 = always the latency schedule (two stages, asm DMA prefetch);
+ *                         4 = X-stationary schedule where K = 512 (X fragments resident in VGPRs, W streamed).
+ *                         Results are bit-identical across schedules.
  * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention, 1 (default) or 2. */
 enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1 };
 int d3pm_set_tuning(int knob, int value);

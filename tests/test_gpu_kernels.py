@@ -33,7 +33,7 @@ def gelu32(v):
     return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
 
 
-@pytest.fixture(params=[2, 3], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency"}[v])
+@pytest.fixture(params=[2, 3, 4], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency", 4: "gemm_xstationary"}[v])
 def gemm_variant(request, built_lib):
     """Both schedules of the MFMA GEMM must pass the same numerics (auto selection is restored afterwards)."""
     from vall_e.vall_e import _hip
@@ -106,11 +106,11 @@ def test_gemm_schedules_are_bit_identical(built_lib):
     w = (torch.randn(1536, 512, generator=g) / math.sqrt(512)).to(torch.bfloat16).to(DEV)
     b = torch.randn(1536, generator=g).to(torch.bfloat16).to(DEV)
     outs = []
-    for v in (2, 3):
+    for v in (2, 3, 4):
         _hip.set_gemm_variant(v)
         outs.append(_hip.op_linear(x, w, b, act=1, family=_hip.FAMILY_MFMA).clone())
     _hip.set_gemm_variant(0)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_linear_fp32_generic(built_lib):

@@ -69,8 +69,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 // EPI bits: 1 = exact-erf GELU, 2 = one residual (R1), 4 = two residuals (R1, R2), 8 = frame mask, 16 = ReLU, 32 = SiLU
 constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8, EPI_RELU = 16, EPI_SILU = 32;
 
-template <typename T, int EPI, int NT = 4>
-__device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][4], const T* __restrict__ bias, T* Y, int ldy,
+template <typename T, int EPI, int NT = 4, int MT = 4>
+__device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* __restrict__ bias, T* Y, int ldy,
                                                const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                int mask_period, int M, int N, int mw0, int nw0, int lane) {
   constexpr bool kGelu = EPI & EPI_GELU, kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][4], const T* _
     }
   const int n_last = N >= 4 ? N - 4 : 0;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int m = mw0 + mt * 16 + (lane & 15);
     const int mc = m < M ? m : M - 1;
     const float mk = kMask ? (row_mask[mc % mask_period] ? 1.f : 0.f) : 1.f;
@@ -290,6 +290,103 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128_pf(const T* __restrict__
   epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+
+// ---- X-stationary schedule for K = 512 (d_model of the bench shape): gemm_mfma_xstat ----------------------------
+// PMC says the 128 x 128 schedules are bound by feeding LDS: every workgroup re-stages the same X panel once per
+// n-tile and 42 % of the wave cycles wait on DMA + barriers.  Here a workgroup of 8 waves owns 256 rows of X for
+// its whole life: each wave keeps its 32 rows x 512 k as MFMA fragments in 128 VGPRs (loaded once), and only W
+// is streamed -- 64-row tiles of 64 KiB through a two-slot LDS ring filled by asm-issued global_load_lds (one
+// 1-KiB row per wave-instruction, chunk index XOR-ed with row & 15 on the source address: conflict-free
+// ds_read_b128 of the fragments), next tile in flight under the 128 MFMAs per wave of the current one.
+// L2 -> LDS bytes per flop drop ~4x; two waves per SIMD let one wave's epilogue hide under the other's MFMAs.
+// Arithmetic per output element is identical to the other schedules (k ascending), results are bit-identical.
+constexpr int XS_ROWS = 256, XS_NT = 64, XS_K = 512, XS_SLOT = XS_NT * XS_K * 2;   // 64 KiB per ring slot
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_mfma_xstat(const T* __restrict__ X, int ldx, const T* __restrict__ W,
+                                                          const T* __restrict__ bias, T* Y, int ldy, const T* R1,
+                                                          const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
+                                                          int mask_period, int M, int N, int tiles_per_wg, int n_slices) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane & 15, g = lane >> 4;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = bid % n_slices, m0 = (bid / n_slices) * XS_ROWS;
+  const int n_tiles_total = (N + XS_NT - 1) / XS_NT;
+  const int tile0 = slice * tiles_per_wg;
+  const int n_my = min(tiles_per_wg, n_tiles_total - tile0);
+  if (n_my <= 0) return;                                          // block-uniform
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+
+  // W ring: wave fills rows 8*wave .. 8*wave+7 of each 64-row tile (one row = 1 KiB = one DMA instruction)
+  auto issue = [&](int j, int slot) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = wave * 8 + i;
+      int n = (tile0 + j) * XS_NT + r;
+      n = n < N ? n : N - 1;
+      glds16_asm(W + static_cast<size_t>(n) * XS_K + ((lane ^ (r & 15)) << 3), lds_base + slot * XS_SLOT + r * 1024);
+    }
+  };
+  // fragment read offsets: row nt*16 + q, chunk (4*ks + g) ^ q  -> lane part for ks & 3, immediates for the rest
+  int xoff[4];
+#pragma unroll
+  for (int k4 = 0; k4 < 4; ++k4) xoff[k4] = q * 1024 + (((4 * k4 + g) ^ q) << 4);
+
+  floatx4 acc[4][2];
+  issue(0, 0);                                             // first W tile on its way while X is fetched
+  // resident X fragments (B operand of D = W_frag . X_frag^T): rows m0 + 32*wave + 16*mt + q, k = 32*ks + 8*g ..
+  uint4 xa[2][16];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int row = m0 + wave * 32 + mt * 16 + q;
+    row = row < M ? row : M - 1;
+    const T* xr = X + static_cast<size_t>(row) * ldx + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) xa[mt][ks] = *reinterpret_cast<const uint4*>(xr + ks * 32);
+  }
+
+  // pin every X fragment as "used" here: hipcc then waits for these loads once, before the loop, instead of
+  // re-executing counted vmcnt waits inside it (which would also drain the W tile kept in flight)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      asm volatile("" : "+v"(xa[mt][ks].x), "+v"(xa[mt][ks].y), "+v"(xa[mt][ks].z), "+v"(xa[mt][ks].w));
+  for (int j = 0; j < n_my; ++j) {
+    if (j + 1 < n_my) {
+      issue(j + 1, (j + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // everything older than the 8 DMAs just issued has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                          // all eight waves' rows of tile j are in LDS
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const char* slot = smem + (j & 1) * XS_SLOT;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      uint4 fw[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        fw[nt] = *reinterpret_cast<const uint4*>(slot + nt * 16384 + xoff[ks & 3] + (ks >> 2) * 256);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mma<T>(fw[nt], xa[mt][ks], acc[nt][mt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // slot j&1 may be refilled (by issue(j+2) next iteration)
+    epilogue_store<T, EPI, 4, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wave * 32,
+                                 (tile0 + j) * XS_NT, lane);
+  }
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -310,16 +407,31 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
-static int g_gemm_variant = 0;   // 0 auto (latency schedule for M <= 1536, else throughput), 2 throughput, 3 latency
+static int g_gemm_variant = 0;   // 0 auto, 2 throughput, 3 latency, 4 X-stationary (K = 512 only)
+static bool g_xstat_auto = false;   // flipped to true once measured faster (D3PM_TUNE_GEMM_VARIANT 4 forces it)
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   // Both schedules accumulate in the same order, so the choice never changes a bit of the result.
   const bool ffn_act = a.act == ACT_RELU || a.act == ACT_SILU;
-  const bool latency = !ffn_act && (g_gemm_variant == 3 || (g_gemm_variant == 0 && a.M <= 1536));
-  const int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
-  const size_t lds = (latency ? 4 : 2) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
+  const bool xstat = a.K == XS_K && !ffn_act && (g_gemm_variant == 4 || (g_gemm_variant == 0 && g_xstat_auto && a.M >= 4096));
+  const bool latency = !xstat && !ffn_act && (g_gemm_variant == 3 || (g_gemm_variant == 0 && a.M <= 1536));
+  int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
+  size_t lds = (latency ? 4 : 2) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
   dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(256);
+  int xs_tiles_per_wg = 0, xs_slices = 1;
+  if (xstat) {
+    // one workgroup (8 waves, 256 rows) per CU: split N into as many slices as keep <= 256 workgroups in flight
+    m_tiles = (a.M + XS_ROWS - 1) / XS_ROWS;
+    const int nt64 = (a.N + XS_NT - 1) / XS_NT;
+    xs_slices = 256 / m_tiles;
+    xs_slices = xs_slices < 1 ? 1 : (xs_slices > nt64 ? nt64 : xs_slices);
+    xs_tiles_per_wg = (nt64 + xs_slices - 1) / xs_slices;
+    xs_slices = (nt64 + xs_tiles_per_wg - 1) / xs_tiles_per_wg;
+    grid = dim3(static_cast<unsigned>(m_tiles) * xs_slices);
+    block = dim3(512);
+    lds = 2 * XS_SLOT;
+  }
   const int epi = (a.act == ACT_GELU ? EPI_GELU : a.act == ACT_RELU ? EPI_RELU : a.act == ACT_SILU ? EPI_SILU : 0) |
                   (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
 
@@ -328,7 +440,7 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
       D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),                           \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XS_SLOT));             \
       attr_set = true;                                                                                          \
     }                                                                                                           \
     __VA_ARGS__<<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),        \
@@ -337,9 +449,24 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
                                          a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles);                    \
     return D3PM_OK;                                                                                             \
   } while (0)
+#define D3PM_GEMM_XS(...)                                                                                       \
+  do {                                                                                                          \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),                           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XS_SLOT));             \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    __VA_ARGS__<<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),        \
+                                         static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,            \
+                                         static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr,       \
+                                         a.row_mask, a.mask_period, a.M, a.N, xs_tiles_per_wg, xs_slices);      \
+    return D3PM_OK;                                                                                             \
+  } while (0)
 #define D3PM_GEMM_EPI(E)                                  \
   do {                                                    \
-    if (latency) D3PM_GEMM(gemm_mfma_128_pf<U, E>);       \
+    if (xstat) D3PM_GEMM_XS(gemm_mfma_xstat<U, E>);       \
+    else if (latency) D3PM_GEMM(gemm_mfma_128_pf<U, E>);  \
     else D3PM_GEMM(gemm_mfma_128_glds<U, E>);             \
   } while (0)
   auto go = [&](auto* tag) -> int {
@@ -357,6 +484,7 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
     return D3PM_E_SHAPE;
   };
 #undef D3PM_GEMM_EPI
+#undef D3PM_GEMM_XS
   int rc = dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
   if (rc != D3PM_OK) return rc;
 #undef D3PM_GEMM
