@@ -53,7 +53,6 @@ template <> __device__ __forceinline__ floatx4 mma<bf16>(uint4 a, uint4 b, float
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
-template <typename T> struct Pack4 { T v[4]; };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap the linear block
 // id so that each XCD walks a contiguous range of tiles: the n-tiles of one 128-row X panel then hit the same
@@ -63,67 +62,119 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// Epilogue on the accumulator layout D[n = nt*16 + (lane>>4)*4 + r][m = mt*16 + (lane&15)]: a lane owns 4
-// consecutive columns of one row per (mt, nt).  Residual loads are branch-free (clamped addresses) and
-// batched per row so that four 8-byte loads are in flight together; only the stores are predicated.
+// Epilogue.  The MFMA leaves D[n = nt*16 + (lane>>4)*4 + r][m = mt*16 + (lane&15)] in a lane: 4 consecutive
+// columns of one row per (nt, mt), i.e. 8-byte stores that touch 32 contiguous bytes per row and instruction.
+// v_permlane16_swap between the accumulators of column blocks nt and nt+1 (odd 16-lane rows of the first operand
+// trade places with the even rows of the second) regroups them so that a lane owns 8 consecutive columns
+//   n = (nt + (g&1))*16 + (g>>1)*8 .. +7,   g = lane>>4,
+// after bias + activation (elementwise, so the order does not matter): residuals and the output then move as
+// 16-byte accesses, half the store instructions and 64 contiguous bytes per row and instruction (the store tail is
+// issue-bound, MI355X_MICROARCH.md constants table).  Values and rounding points are untouched -- the swap only
+// changes which lane finishes which element.
+// The swap is inline asm on purpose: with hipcc 7.2 the two-result __builtin_amdgcn_permlane16_swap loses its second
+// result once the operands are floats in an unrolled loop (both halves read the first output register; seen in the
+// .s of a 10-line kernel and as 50 % wrong columns on the GPU).  `s_nop 1` covers the VALU-write -> permlane-read
+// hazard the compiler cannot see inside the string; the operands are always produced by the bias add (VALU), never
+// directly by an MFMA.
+// Residual loads are branch-free (clamped addresses) and batched per row; only the stores are predicated.
 // EPI bits: 1 = exact-erf GELU, 2 = one residual (R1), 4 = two residuals (R1, R2), 8 = frame mask, 16 = ReLU, 32 = SiLU
 constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8, EPI_RELU = 16, EPI_SILU = 32;
+
+template <typename T> struct alignas(8) Pack4 { T v[4]; };
+template <typename T> struct alignas(16) Pack8 { T v[8]; };
+
+__device__ __forceinline__ void swap_rows16(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 
 template <typename T, int EPI, int NT = 4, int MT = 4>
 __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* __restrict__ bias, T* Y, int ldy,
                                                const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                int mask_period, int M, int N, int mw0, int nw0, int lane) {
+  static_assert(NT % 2 == 0, "column blocks are regrouped in pairs");
   constexpr bool kGelu = EPI & EPI_GELU, kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
-  const int nq = (lane >> 4) * 4;
+  constexpr int NP = NT / 2;
+  const int g = lane >> 4;
+  const int nq = (g & 1) * 16 + (g >> 1) * 8;           // column of this lane's 8-group inside a 32-column pair
+  // bias in the MFMA layout (applied before the regrouping).  Loads are branch-free per lane -- clamped addresses,
+  // one batch, one wait: per-element predicated loads compile to sixteen serialized L2 round trips.
   float bv[NT][4];
+  if (bias == nullptr) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = nw0 + nt * 16 + nq + r;
-      bv[nt][r] = (bias && n < N) ? static_cast<float>(bias[n]) : 0.f;
+      for (int r = 0; r < 4; ++r) bv[nt][r] = 0.f;
+  } else if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(bias) & 7) == 0) {
+    Pack4<T> pb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nw0 + nt * 16 + g * 4;
+      pb[nt] = *reinterpret_cast<const Pack4<T>*>(bias + (n < N ? n : N - 4));
     }
-  const int n_last = N >= 4 ? N - 4 : 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[nt][r] = static_cast<float>(pb[nt].v[r]);   // columns >= N are never stored
+  } else {
+    T sb[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nw0 + nt * 16 + g * 4 + r;
+        sb[nt][r] = bias[n < N ? n : N - 1];
+      }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[nt][r] = static_cast<float>(sb[nt][r]);
+  }
+  const int n_last = N >= 8 ? N - 8 : 0;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mw0 + mt * 16 + (lane & 15);
     const int mc = m < M ? m : M - 1;
     const float mk = kMask ? (row_mask[mc % mask_period] ? 1.f : 0.f) : 1.f;
-    Pack4<T> p1[NT], p2[NT];
-    if (kR1) {   // N % 4 == 0 is guaranteed by mfma_linear_supported when a residual is given
+    Pack8<T> p1[NP], p2[NP];
+    if (kR1) {   // N % 8 == 0 is guaranteed by mfma_linear_supported when a residual is given
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        int nc = nw0 + nt * 16 + nq;
+      for (int np = 0; np < NP; ++np) {
+        int nc = nw0 + np * 32 + nq;
         nc = nc < n_last ? nc : n_last;
-        p1[nt] = *reinterpret_cast<const Pack4<T>*>(R1 + static_cast<size_t>(mc) * ldr + nc);
-        if (kR2) p2[nt] = *reinterpret_cast<const Pack4<T>*>(R2 + static_cast<size_t>(mc) * ldr + nc);
+        p1[np] = *reinterpret_cast<const Pack8<T>*>(R1 + static_cast<size_t>(mc) * ldr + nc);
+        if (kR2) p2[np] = *reinterpret_cast<const Pack8<T>*>(R2 + static_cast<size_t>(mc) * ldr + nc);
       }
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nw0 + nt * 16 + nq;
-      float v[4];
+    for (int np = 0; np < NP; ++np) {
+      const int n = nw0 + np * 32 + nq;
+      float v[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = rn<T>(acc[nt][mt][r] + bv[nt][r]);
+      for (int r = 0; r < 8; ++r) {
+        v[r] = rn<T>(acc[2 * np + (r >> 2)][mt][r & 3] + bv[2 * np + (r >> 2)][r & 3]);
         if (kGelu) v[r] = rn<T>(gelu_erf(v[r]));
         if (EPI & EPI_RELU) v[r] = fmaxf(v[r], 0.f);
         if (EPI & EPI_SILU) v[r] = rn<T>(v[r] / (1.0f + expf(-v[r])));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) swap_rows16(v[r], v[4 + r]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
         if (kR1) {
-          float res = static_cast<float>(p1[nt].v[r]);
-          if (kR2) res = rn<T>(res + static_cast<float>(p2[nt].v[r]));
+          float res = static_cast<float>(p1[np].v[r]);
+          if (kR2) res = rn<T>(res + static_cast<float>(p2[np].v[r]));
           v[r] = rn<T>(res + v[r]);
         }
       }
       if (m < M && n < N) {
         T* y = Y + static_cast<size_t>(m) * ldy + n;
-        if (n + 3 < N) {
-          Pack4<T> o;
+        if (n + 7 < N) {
+          Pack8<T> o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o.v[r] = static_cast<T>(v[r] * mk);
-          *reinterpret_cast<Pack4<T>*>(y) = o;
+          for (int r = 0; r < 8; ++r) o.v[r] = static_cast<T>(v[r] * mk);
+          *reinterpret_cast<Pack8<T>*>(y) = o;
         } else {
-          for (int r = 0; r < 4 && n + r < N; ++r) y[r] = static_cast<T>(v[r] * mk);
+          for (int r = 0; r < 8 && n + r < N; ++r) y[r] = static_cast<T>(v[r] * mk);
         }
       }
     }
@@ -319,14 +370,16 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_xstat(const T* __restrict__ 
   if (n_my <= 0) return;                                          // block-uniform
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
 
-  // W ring: wave fills rows 8*wave .. 8*wave+7 of each 64-row tile (one row = 1 KiB = one DMA instruction)
+  // W ring: wave fills rows i*8 + wave (i = 0..7) of each 64-row tile, one row = 1 KiB = one DMA instruction.  The
+  // swizzle key of a row is r & 15 = (i & 1) * 8 + wave: two per-lane source offsets cover all eight instructions.
+  const int key0 = lane ^ wave, key1 = lane ^ (wave + 8);
   auto issue = [&](int j, int slot) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int r = wave * 8 + i;
+      const int r = i * 8 + wave;
       int n = (tile0 + j) * XS_NT + r;
       n = n < N ? n : N - 1;
-      glds16_asm(W + static_cast<size_t>(n) * XS_K + ((lane ^ (r & 15)) << 3), lds_base + slot * XS_SLOT + r * 1024);
+      glds16_asm(W + static_cast<size_t>(n) * XS_K + (((i & 1) ? key1 : key0) << 3), lds_base + slot * XS_SLOT + r * 1024);
     }
   };
   // fragment read offsets: row nt*16 + q, chunk (4*ks + g) ^ q  -> lane part for ks & 3, immediates for the rest
@@ -363,28 +416,48 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_xstat(const T* __restrict__ 
     }
     __builtin_amdgcn_s_barrier();                          // all eight waves' rows of tile j are in LDS
     __builtin_amdgcn_sched_barrier(0);
+    // the previous tile's epilogue runs HERE, not right after its MFMAs: its stores then have the whole MFMA phase
+    // of tile j to retire before the next counted vmcnt (gfx950 counts stores in vmcnt)
+    if (j > 0)
+      epilogue_store<T, EPI, 4, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wave * 32,
+                                   (tile0 + j - 1) * XS_NT, lane);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
     const char* slot = smem + (j & 1) * XS_SLOT;
+    // W fragments are double-buffered by hand (fw[ks & 1]): left to itself hipcc funnels all 64 LDS reads of a tile
+    // through one register quad with lgkmcnt(0) before every MFMA pair, i.e. fully exposed LDS latency
+    uint4 fw[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) fw[0][nt] = *reinterpret_cast<const uint4*>(slot + nt * 16384 + xoff[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);         // k-step 0's reads lead the pipeline
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      uint4 fw[4];
+      if (ks + 1 < 16) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          fw[(ks + 1) & 1][nt] =
+              *reinterpret_cast<const uint4*>(slot + nt * 16384 + xoff[(ks + 1) & 3] + ((ks + 1) >> 2) * 256);
+      }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
-        fw[nt] = *reinterpret_cast<const uint4*>(slot + nt * 16384 + xoff[ks & 3] + (ks >> 2) * 256);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mma<T>(fw[ks & 1][nt], xa[mt][ks], acc[nt][mt]);
+      if (ks + 1 < 16) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mma<T>(fw[nt], xa[mt][ks], acc[nt][mt]);
+        for (int nt = 0; nt < 4; ++nt) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read of the next k-step ...
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // ... under two MFMAs of this one
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // slot j&1 may be refilled (by issue(j+2) next iteration)
-    epilogue_store<T, EPI, 4, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wave * 32,
-                                 (tile0 + j) * XS_NT, lane);
   }
+  epilogue_store<T, EPI, 4, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wave * 32,
+                               (tile0 + n_my - 1) * XS_NT, lane);
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -394,9 +467,9 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
   if (a.M < 1 || a.N < 1 || a.K < BK || a.K % BK != 0) return false;
-  if (a.ldx % 8 != 0 || a.ldy % 4 != 0 || !aligned(a.X, 16) || !aligned(a.W, 16) || !aligned(a.Y, 8)) return false;
-  if (a.R1 && (a.ldr % 4 != 0 || a.N % 4 != 0 || !aligned(a.R1, 8))) return false;
-  if (a.R2 && !aligned(a.R2, 8)) return false;
+  if (a.ldx % 8 != 0 || a.ldy % 8 != 0 || !aligned(a.X, 16) || !aligned(a.W, 16) || !aligned(a.Y, 16)) return false;
+  if (a.R1 && (a.ldr % 8 != 0 || a.N % 8 != 0 || !aligned(a.R1, 16))) return false;
+  if (a.R2 && !aligned(a.R2, 16)) return false;
   if (static_cast<long long>(a.M) * a.N < 128 * 128) return false;     // not worth a 128^2 tile
   const bool gelu = a.act == ACT_GELU, r1 = a.R1 != nullptr, r2 = a.R2 != nullptr, mk = a.row_mask != nullptr;
   if (a.act == ACT_RELU || a.act == ACT_SILU) return !r1 && !mk;   // condition-encoder FFN epilogues
