@@ -46,10 +46,17 @@ def main():
         y = torch.empty(M, ldy, device=DEV, dtype=dtype)
         r = torch.randn(M, ldy, device=DEV).to(dtype) if res else None
         line = f"{name:10s} N={N:5d} K={K:5d}"
-        for variant in ((2,) if quick else (2, 4)):
+        for variant in ((2,) if quick else (2, 5, 3, 4)):
             _hip.set_gemm_variant(variant)
             t = timeit(lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=ldy))
             line += f" | v{variant}: {t * 1e6:7.1f} us {2 * M * N * K / t / 1e12:7.1f} TF/s"
+        if "--slots" in sys.argv:
+            _hip.set_gemm_variant(2)
+            for slots in (512, 768, 1280):
+                _hip.set_gemm_persist_slots(slots)
+                t = timeit(lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=ldy))
+                line += f" | s{slots}: {t * 1e6:6.1f}"
+            _hip.set_gemm_persist_slots(1024)
         print(line, flush=True)
     _hip.set_gemm_variant(0)
     if "--small" in sys.argv or not quick:

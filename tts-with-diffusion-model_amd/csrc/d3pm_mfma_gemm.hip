@@ -51,7 +51,29 @@ template <> __device__ __forceinline__ floatx4 mma<bf16>(uint4 a, uint4 b, float
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+// erf for the GELU epilogue: erf(x) = sign(x) (1 - 2^(-t P(t))), t = min(|x|, 3.95), P a degree-8 fit of
+// -log2(erfc(t))/t (fit error 2e-9, fp32 evaluation within 1.4 * 2^-24 absolute of the exact erf on [-6, 6]).  One
+// straight-line chain of 8 FMAs and one v_exp_f32 instead of libm's two-branch erff: the fc1 epilogue was VALU-bound
+// on erff (2500 of its 3400 vector instructions per wave, 60 of the 95 us of the kernel at 24576 x 2048).  What GELU
+// needs is absolute accuracy of erf at the 2^-24 grid -- the reference's own 1 + erf(x) cancels against that grid in
+// the negative tail -- and there this form is as close to torch's CPU gelu as torch's is to the exact function
+// (tools/fit_erf.py: fp16 7.6e-4 / bf16 9e-5 of N(0,1) inputs round differently, torch-vs-exact 6.2e-4 / 9e-5).
+// The generic (FMA) family keeps libm's erff: it is the numerical specification and the bit-exact native-shape path.
+__device__ __forceinline__ float erf_fit(float x) {
+  const float t = fminf(fabsf(x), 3.95f);
+  float p = -1.1604810424614698e-05f;
+  p = __builtin_fmaf(p, t, 0.00015296436322387308f);
+  p = __builtin_fmaf(p, t, -0.000848234398290515f);
+  p = __builtin_fmaf(p, t, 0.0022747856564819813f);
+  p = __builtin_fmaf(p, t, -8.480551332468167e-05f);
+  p = __builtin_fmaf(p, t, -0.027724476531147957f);
+  p = __builtin_fmaf(p, t, 0.1483079046010971f);
+  p = __builtin_fmaf(p, t, 0.9184429049491882f);
+  p = __builtin_fmaf(p, t, 1.6279072761535645f);
+  const float e = __builtin_amdgcn_exp2f(-(p * t));
+  return __builtin_copysignf(1.0f - e, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fit(v * 0.70710678118654752f)); }
 
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap the linear block
@@ -80,6 +102,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 // EPI bits: 1 = exact-erf GELU, 2 = one residual (R1), 4 = two residuals (R1, R2), 8 = frame mask, 16 = ReLU, 32 = SiLU
 constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8, EPI_RELU = 16, EPI_SILU = 32;
 
+typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+  typedef T pair __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, pair{static_cast<T>(a), static_cast<T>(b)});
+}
 template <typename T> struct alignas(8) Pack4 { T v[4]; };
 template <typename T> struct alignas(16) Pack8 { T v[8]; };
 
@@ -87,7 +114,7 @@ __device__ __forceinline__ void swap_rows16(float& a, float& b) {
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
-template <typename T, int EPI, int NT = 4, int MT = 4>
+template <typename T, int EPI, int NT = 4, int MT = 4, bool kInteriorOnly = false>
 __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* __restrict__ bias, T* Y, int ldy,
                                                const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                int mask_period, int M, int N, int mw0, int nw0, int lane) {
@@ -129,6 +156,58 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[nt][r] = static_cast<float>(sb[nt][r]);
   }
+  auto finish = [&](float (&v)[8], int np, int mt) {   // bias + activation in the MFMA layout, then the regrouping
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r] = rn<T>(acc[2 * np + (r >> 2)][mt][r & 3] + bv[2 * np + (r >> 2)][r & 3]);
+      if (kGelu) v[r] = rn<T>(gelu_erf(v[r]));
+      if (EPI & EPI_RELU) v[r] = fmaxf(v[r], 0.f);
+      if (EPI & EPI_SILU) v[r] = rn<T>(v[r] / (1.0f + expf(-v[r])));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) swap_rows16(v[r], v[4 + r]);
+  };
+  if (kInteriorOnly || (mw0 + MT * 16 <= M && nw0 + NT * 16 <= N)) {
+    // interior wave tile (wave-uniform test): no clamps or predicates, one 64-bit row pointer per operand that
+    // advances by 16 rows, column offsets as instruction immediates
+    const int m = mw0 + (lane & 15);
+    T* y = Y + static_cast<size_t>(m) * ldy + nw0 + nq;
+    const T* r1 = kR1 ? R1 + static_cast<size_t>(m) * ldr + nw0 + nq : nullptr;
+    const T* r2 = kR2 ? R2 + static_cast<size_t>(m) * ldr + nw0 + nq : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float mk = kMask ? (row_mask[(m + mt * 16) % mask_period] ? 1.f : 0.f) : 1.f;
+      Pack8<T> p1[NP], p2[NP];
+      if (kR1) {
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+          p1[np] = *reinterpret_cast<const Pack8<T>*>(r1 + np * 32);
+          if (kR2) p2[np] = *reinterpret_cast<const Pack8<T>*>(r2 + np * 32);
+        }
+      }
+#pragma unroll
+      for (int np = 0; np < NP; ++np) {
+        float v[8];
+        finish(v, np, mt);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          if (kR1) {
+            float res = static_cast<float>(p1[np].v[r]);
+            if (kR2) res = rn<T>(res + static_cast<float>(p2[np].v[r]));
+            v[r] = rn<T>(res + v[r]);
+          }
+          if (kMask) v[r] *= mk;
+        }
+        *reinterpret_cast<uintx4*>(y + np * 32) =
+            uintx4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+      }
+      y += static_cast<size_t>(16) * ldy;
+      if (kR1) r1 += static_cast<size_t>(16) * ldr;
+      if (kR2) r2 += static_cast<size_t>(16) * ldr;
+    }
+    return;
+  }
+  if constexpr (kInteriorOnly) return;   // the persistent schedule is only ever launched over whole tiles
   const int n_last = N >= 8 ? N - 8 : 0;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -149,15 +228,7 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
     for (int np = 0; np < NP; ++np) {
       const int n = nw0 + np * 32 + nq;
       float v[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        v[r] = rn<T>(acc[2 * np + (r >> 2)][mt][r & 3] + bv[2 * np + (r >> 2)][r & 3]);
-        if (kGelu) v[r] = rn<T>(gelu_erf(v[r]));
-        if (EPI & EPI_RELU) v[r] = fmaxf(v[r], 0.f);
-        if (EPI & EPI_SILU) v[r] = rn<T>(v[r] / (1.0f + expf(-v[r])));
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) swap_rows16(v[r], v[4 + r]);
+      finish(v, np, mt);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         if (kR1) {
@@ -249,7 +320,16 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128_glds(const T* __restrict
     }
     __syncthreads();
   }
+#ifndef D3PM_EXP_NOSTORE
   epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+#else
+  {  // ablation build (tests/bench_kernels.py), never shipped: keep every accumulator live, store nothing
+    float sum = 0.f;
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 4; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (sum == 12345.f) Y[0] = static_cast<T>(1.f);
+  }
+#endif
 }
 
 
@@ -338,7 +418,128 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128_pf(const T* __restrict__
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of tile kt retired
     __builtin_amdgcn_s_barrier();                        // barrier B: tile kt's buffer may be overwritten
   }
+#ifndef D3PM_EXP_NOSTORE
   epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+#else
+  {  // ablation build (tests/bench_kernels.py), never shipped: keep every accumulator live, store nothing
+    float sum = 0.f;
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 4; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (sum == 12345.f) Y[0] = static_cast<T>(1.f);
+  }
+#endif
+}
+
+
+// ---- persistent throughput schedule over whole 128 x 128 tiles: gemm_mfma_128_persist --------------------------
+// Measured on the one-tile-per-workgroup kernel (24576 x 1536 x 512 bf16): main loop alone 36.5 us, the 75 MB of
+// stores alone 13.5 us, together 47.9 us -- the four co-resident workgroups run in phase (same start, same tile
+// time, 2.25 rounds), so every CU alternates between "all loading / MFMA" and "all storing".  Here a workgroup stays
+// resident and walks the tiles of its XCD: the first k-step of the NEXT tile is put in flight before the epilogue,
+// and the epilogue's stores are left in flight into the next tile's first k-step (counted vmcnt: the 8 stores of an
+// interior wave tile are the youngest operations, everything older -- the DMA -- has landed).  Ragged edge tiles go
+// through gemm_mfma_128_glds in a second launch, so this kernel carries no clamps and no predicated epilogue.
+// DMA sources are a uniform tile base (SGPR pair) plus a tile-invariant 32-bit per-lane offset.
+__device__ __forceinline__ void glds16_asm_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 4) void gemm_mfma_128_persist(const T* __restrict__ X, int ldx, const T* __restrict__ W,
+                                                                const T* __restrict__ bias, T* Y, int ldy, const T* R1,
+                                                                const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
+                                                                int mask_period, int M, int N, int K, int n_tiles,
+                                                                int tiles_total) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD x = blockIdx & 7 owns a contiguous range of tiles (the n-tiles of one X panel then share an L2)
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  const int tq = tiles_total >> 3, tr = tiles_total & 7;
+  const int lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, cnt = tq + (xcd < tr ? 1 : 0);
+  int t = blockIdx.x >> 3;
+  if (t >= cnt) return;                                            // block-uniform
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem)) +
+                            wave * 4096;
+  uint32_t ox[4], ow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    ox[i] = static_cast<uint32_t>(row * ldx + logical * 8) * 2u;
+    ow[i] = static_cast<uint32_t>(row * K + logical * 8) * 2u;
+  }
+  const int frow = lane & 15, fch = lane >> 4;
+  const int nk = K / BK;
+  const char* bufA = smem;
+  const char* bufB = bufA + TILE_BYTES;
+  int tile = lo + t;
+  const T* sx = X + static_cast<size_t>((tile / n_tiles) * BM) * ldx;
+  const T* sw = W + static_cast<size_t>((tile % n_tiles) * BN) * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    glds16_asm_s(sx, ox[i], lds_base + i * 1024);
+    glds16_asm_s(sw, ow[i], lds_base + TILE_BYTES + i * 1024);
+  }
+  bool first = true;
+  for (;;) {
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          glds16_asm_s(sx + kt * BK, ox[i], lds_base + i * 1024);
+          glds16_asm_s(sw + kt * BK, ow[i], lds_base + TILE_BYTES + i * 1024);
+        }
+      }
+      if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // previous tile's 8 stores stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                      // every wave's share of the k-step is in LDS
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 fx[4], fw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          fx[q] = *reinterpret_cast<const uint4*>(bufA + lds_off(wm * 64 + q * 16 + frow, ks * 4 + fch));
+          fw[q] = *reinterpret_cast<const uint4*>(bufB + lds_off(wn * 64 + q * 16 + frow, ks * 4 + fch));
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all fragment reads retired
+      __builtin_amdgcn_s_barrier();                       // the stage may be overwritten
+    }
+    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+    t += per_xcd;
+    const bool more = t < cnt;                            // block-uniform
+    if (more) {
+      tile = lo + t;
+      sx = X + static_cast<size_t>((tile / n_tiles) * BM) * ldx;
+      sw = W + static_cast<size_t>((tile % n_tiles) * BN) * K;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        glds16_asm_s(sx, ox[i], lds_base + i * 1024);
+        glds16_asm_s(sw, ow[i], lds_base + TILE_BYTES + i * 1024);
+      }
+    }
+    epilogue_store<T, EPI, 4, 4, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64,
+                                       n0 + wn * 64, lane);
+    if (!more) break;
+    first = false;
+  }
 }
 
 
@@ -480,9 +681,11 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
-static int g_gemm_variant = 0;   // 0 auto, 2 throughput, 3 latency, 4 X-stationary (K = 512 only)
+static int g_gemm_variant = 0;   // 0 auto, 2 throughput (persistent over whole tiles), 3 latency, 4 X-stationary (K = 512 only), 5 throughput with one tile per workgroup
+static int g_persist_slots = 1024;   // resident workgroups of the persistent schedule: 4 per CU x 256 CUs
 static bool g_xstat_auto = false;   // flipped to true once measured faster (D3PM_TUNE_GEMM_VARIANT 4 forces it)
 void set_gemm_variant(int v) { g_gemm_variant = v; }
+void set_gemm_persist_slots(int v) { g_persist_slots = v; }
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   // Both schedules accumulate in the same order, so the choice never changes a bit of the result.
@@ -490,6 +693,12 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   const bool xstat = a.K == XS_K && !ffn_act && (g_gemm_variant == 4 || (g_gemm_variant == 0 && g_xstat_auto && a.M >= 4096));
   const bool latency = !xstat && !ffn_act && (g_gemm_variant == 3 || (g_gemm_variant == 0 && a.M <= 1536));
   int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
+  // shapes made of whole tiles go through the persistent kernel once there are enough tiles to fill the chip twice
+  // over (a ragged edge would need a second launch that costs more than persistence gains: measured on N = 1025)
+  const int n_full = a.N / BN, m_full = a.M / BM;
+  const bool persist = !xstat && !latency && !ffn_act && (g_gemm_variant == 0 || g_gemm_variant == 2) &&
+                       a.M % BM == 0 && a.N % BN == 0 && static_cast<long long>(n_full) * m_full >= 2 * 256 &&
+                       static_cast<long long>(BM) * a.ldx * 2 < (1ll << 31) && static_cast<long long>(BN) * a.K * 2 < (1ll << 31);
   size_t lds = (latency ? 4 : 2) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
   dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(256);
   int xs_tiles_per_wg = 0, xs_slices = 1;
@@ -536,10 +745,25 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
                                          a.row_mask, a.mask_period, a.M, a.N, xs_tiles_per_wg, xs_slices);      \
     return D3PM_OK;                                                                                             \
   } while (0)
+#define D3PM_GEMM_PERSIST(E)                                                                                    \
+  do {                                                                                                          \
+    const int want = (m_full * n_full + 7) & ~7;                                                                \
+    const dim3 pgrid(static_cast<unsigned>(want < g_persist_slots ? want : g_persist_slots));                   \
+    const U* X = static_cast<const U*>(a.X);                                                                    \
+    const U* Wp = static_cast<const U*>(a.W);                                                                   \
+    const U* bp = static_cast<const U*>(a.bias);                                                                \
+    U* Yp = static_cast<U*>(a.Y);                                                                               \
+    const U* r1 = static_cast<const U*>(a.R1);                                                                  \
+    const U* r2 = static_cast<const U*>(a.R2);                                                                  \
+    gemm_mfma_128_persist<U, E><<<pgrid, block, lds, s>>>(X, a.ldx, Wp, bp, Yp, a.ldy, r1, r2, a.ldr, a.row_mask, \
+                                                          a.mask_period, a.M, a.N, a.K, n_full, m_full * n_full); \
+    return D3PM_OK;                                                                                             \
+  } while (0)
 #define D3PM_GEMM_EPI(E)                                  \
   do {                                                    \
     if (xstat) D3PM_GEMM_XS(gemm_mfma_xstat<U, E>);       \
     else if (latency) D3PM_GEMM(gemm_mfma_128_pf<U, E>);  \
+    else if (persist) D3PM_GEMM_PERSIST(E);               \
     else D3PM_GEMM(gemm_mfma_128_glds<U, E>);             \
   } while (0)
   auto go = [&](auto* tag) -> int {
@@ -557,6 +781,7 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
     return D3PM_E_SHAPE;
   };
 #undef D3PM_GEMM_EPI
+#undef D3PM_GEMM_PERSIST
 #undef D3PM_GEMM_XS
   int rc = dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
   if (rc != D3PM_OK) return rc;

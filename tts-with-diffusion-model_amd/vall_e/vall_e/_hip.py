@@ -17,8 +17,8 @@ FLAG_GREEDY, FLAG_FORCE_GENERIC = 1, 2
 K_GEMM, K_ATTN, K_SAMPLE, K_LN = 0, 1, 2, 3
 
 _DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
-LIB_PATH = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "lib",
-                                         "libd3pm_hip.so"))
+LIB_PATH = os.environ.get("D3PM_HIP_LIB") or os.path.normpath(
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "lib", "libd3pm_hip.so"))
 
 
 class Shape(C.Structure):
@@ -432,6 +432,10 @@ def set_gemm_variant(v: int):
 
 def set_attn_query_groups(v: int):
     check(lib().d3pm_set_tuning(1, v), "d3pm_set_tuning")
+
+
+def set_gemm_persist_slots(v: int):
+    check(lib().d3pm_set_tuning(2, v), "d3pm_set_tuning")
 
 
 def prof_enable(kclass: int, max_events: int):
