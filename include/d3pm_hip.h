@@ -261,7 +261,8 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *                         4 = X-stationary schedule where K = 512 (X fragments resident in VGPRs, W streamed);
  *                         5 = throughput schedule with one tile per workgroup (the non-persistent form of 2).
  *                         Results are bit-identical across schedules.
- * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention, 1 (default) or 2.
+ * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention: 0 = auto (default: 2 when that still
+ *                         gives >= 4 workgroups per CU, else 1), 1 or 2.
  * D3PM_TUNE_GEMM_PERSIST_SLOTS: resident workgroups of the persistent throughput schedule, a multiple of 8
  *                         (default 1024 = 4 per CU). */
 enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2 };

@@ -48,7 +48,7 @@ def attn_qg(request, built_lib):
     from vall_e.vall_e import _hip
     _hip.set_attn_query_groups(request.param)
     yield request.param
-    _hip.set_attn_query_groups(1)
+    _hip.set_attn_query_groups(0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -49,6 +49,21 @@ template <> __device__ __forceinline__ floatx4 mma<bf16>(uint4 a, uint4 b, float
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * ROWB + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
 
+constexpr float kDefer = 8.0f;   // log2 of the largest un-normalised probability tolerated before m_ref is raised
+
+// max over the four lanes l, l^16, l^32, l^48 on the VALU (no LDS round trip): after v_permlane16_swap of two copies
+// one holds the even 16-lane rows twice and the other the odd rows twice; v_permlane32_swap does the same for halves.
+// Inline asm: see the note on the two-result builtin in d3pm_mfma_gemm.hip; s_nop 1 = the VALU-write hazard.
+__device__ __forceinline__ float max_over_query_lanes(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  x = fmaxf(a, b);
+  a = x;
+  b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+
 // two floats -> one packed 16-bit pair; the vector conversion lowers to a single v_cvt_pk_{bf16,f16}_f32
 template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
   typedef float float2v __attribute__((ext_vector_type(2)));
@@ -57,7 +72,7 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
 }
 
 template <typename T, int QG>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
-__global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
+__global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
                                                       const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo,
                                                       int Tq, int S, float scale, int H, int n_qblocks,
                                                       const T* __restrict__ Q2, const T* __restrict__ K2,
@@ -133,13 +148,14 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
   store_tile(smem, st);
   __syncthreads();
 
-  float m_run[QG];
-  floatx4 acc_o[QG][4], acc_l[QG];
+  float m_ref[QG];
+  floatx4 negm[QG], acc_o[QG][4], acc_l[QG];
   const uint32_t one2 = pack2<T>(1.0f, 1.0f);
   const uint4 ones = uint4{one2, one2, one2, one2};
 #pragma unroll
   for (int qg = 0; qg < QG; ++qg) {
-    m_run[qg] = -INFINITY;
+    m_ref[qg] = 0.f;
+    negm[qg] = floatx4{0.f, 0.f, 0.f, 0.f};
     acc_l[qg] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc_o[qg][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -152,20 +168,18 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
     if (more) st = load_tile(tile + 1);
 
     // ---- S^T tile: 64 keys x (16 QG) queries per wave; each K fragment feeds QG MFMAs ----
+    // The accumulator starts at -m_ref (one register quad per query group, shared by the four key tiles as the C
+    // operand), so the scores leave the matrix pipe already relative to the running reference: no subtraction.
     floatx4 s[QG][4];
-#pragma unroll
-    for (int qg = 0; qg < QG; ++qg)
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) s[qg][kt] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         uint4 kf = *reinterpret_cast<const uint4*>(kb + k_off(kt * 16 + qi, ks * 4 + g));
 #pragma unroll
-        for (int qg = 0; qg < QG; ++qg) s[qg][kt] = mma<T>(kf, qf[qg][ks], s[qg][kt]);
+        for (int qg = 0; qg < QG; ++qg) s[qg][kt] = mma<T>(kf, qf[qg][ks], ks == 0 ? negm[qg] : s[qg][kt]);
       }
-    // lane holds scores (log2 domain) of its query for keys tile*64 + kt*16 + 4g + r
+    // lane holds scores (log2 domain, minus m_ref) of its query for keys tile*64 + kt*16 + 4g + r
     const bool ragged = (tile == n_tiles - 1) && (S & (BKV - 1));   // wave-uniform: only the last tile can be partial
     const int key_base = tile * BKV + 4 * g;
     uint4 pf[QG][2];
@@ -184,23 +198,32 @@ __global__ __launch_bounds__(256) void attn_mfma_hd64(const T* __restrict__ Q, i
         mx = fmaxf(fmaxf(mx, s[qg][kt][0]), s[qg][kt][1]);
         mx = fmaxf(fmaxf(mx, s[qg][kt][2]), s[qg][kt][3]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
-      const float m_new = fmaxf(m_run[qg], mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);      // exp2(-inf) = 0 on the first tile
-      m_run[qg] = m_new;
+      // Deferred maximum: m_ref only moves when some score of the wave exceeds it by more than 2^kDefer (or on the
+      // first tile), so the common tile does neither the cross-lane maximum nor the rescale of O; probabilities are
+      // then at most 2^kDefer instead of 1, which neither fp32 sums nor 16-bit P notice (normalised by the same sum).
+      if (tile == 0 || __any(mx > kDefer)) {               // wave-uniform
+        mx = max_over_query_lanes(mx);                     // lanes l, l^16, l^32, l^48 share a query
+        const float delta = tile == 0 ? mx : fmaxf(mx, 0.f);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[qg][kt][r] -= delta;
+        if (tile != 0) {                                   // on the first tile O and l are still zero
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc_l[qg][r] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_o[qg][dt][r] *= alpha;
+        }
+        m_ref[qg] += delta;
+        negm[qg] = floatx4{-m_ref[qg], -m_ref[qg], -m_ref[qg], -m_ref[qg]};
+      }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[qg][kt][r] = __builtin_amdgcn_exp2f(s[qg][kt][r] - m_new);
-      if (!__all(alpha == 1.0f)) {                       // the running max moved for some query of this wave
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc_l[qg][r] *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc_o[qg][dt][r] *= alpha;
-      }
+        for (int r = 0; r < 4; ++r) s[qg][kt][r] = __builtin_amdgcn_exp2f(s[qg][kt][r]);
       // contraction index j<4 -> key tile 2kb, j>=4 -> key tile 2kb+1 (same permutation as the V reads)
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
@@ -262,11 +285,15 @@ bool mfma_attention_supported(int dtype, const AttnArgs& a) {
   return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 8);
 }
 
-static int g_attn_qg = 1;   // measured: 1 group (64 queries / workgroup) 80.8 us vs 2 groups 90.5 us on the 768x768 self-attention
+// 0 = auto: two 16-query groups per wave (each K / V fragment read from LDS feeds two MFMAs; 63.8 vs 65.8 us on the
+// 768 x 768 x 256-head self-attention, 27.7 vs 30.1 us on the 225-key prompt attention) once that still leaves >= 4
+// workgroups per CU, one group otherwise (a single utterance is 48 workgroups of two groups: latency regime)
+static int g_attn_qg = 0;
 void set_attn_qg(int v) { g_attn_qg = v; }
 
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
-  const int qg = g_attn_qg == 1 ? 1 : 2, per_block = 64 * qg;
+  const long long wgs2 = static_cast<long long>((a.Tq + 127) / 128) * a.H * a.B * (a.Q2 ? 2 : 1);
+  const int qg = g_attn_qg == 0 ? (wgs2 >= 4 * 256 ? 2 : 1) : g_attn_qg, per_block = 64 * qg;
   const int n_qblocks = (a.Tq + per_block - 1) / per_block;
   const int n_first = n_qblocks * a.H * a.B;
   dim3 grid(static_cast<unsigned>(n_first) * (a.Q2 ? 2 : 1)), block(256);
