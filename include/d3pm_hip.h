@@ -256,9 +256,8 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
 /* Tuning knobs (process-wide; defaults are what bench.py measures).
  * D3PM_TUNE_GEMM_VARIANT: 0 = auto (default): latency schedule for M <= 1536 rows, throughput schedule otherwise;
  *                         2 = always the throughput schedule (one LDS stage, 4 workgroups per CU; persistent over the
- *                             whole 128 x 128 tiles once there are >= 512 of them, ragged edges in a second launch);
+ *                             128 x 128 tiles when M and N are multiples of 128 and there are >= 512 tiles, else as 5);
  *                         3 = always the latency schedule (two stages, asm DMA prefetch);
- *                         4 = X-stationary schedule where K = 512 (X fragments resident in VGPRs, W streamed);
  *                         5 = throughput schedule with one tile per workgroup (the non-persistent form of 2).
  *                         Results are bit-identical across schedules.
  * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention: 0 = auto (default: 2 when that still

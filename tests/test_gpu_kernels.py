@@ -33,8 +33,7 @@ def gelu32(v):
     return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
 
 
-@pytest.fixture(params=[2, 3, 4, 5], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency", 4: "gemm_xstationary",
-                                                    5: "gemm_one_tile"}[v])
+@pytest.fixture(params=[2, 3, 5], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency", 5: "gemm_one_tile"}[v])
 def gemm_variant(request, built_lib):
     """Both schedules of the MFMA GEMM must pass the same numerics (auto selection is restored afterwards)."""
     from vall_e.vall_e import _hip
@@ -107,7 +106,7 @@ def test_gemm_schedules_are_bit_identical(built_lib):
     w = (torch.randn(1536, 512, generator=g) / math.sqrt(512)).to(torch.bfloat16).to(DEV)
     b = torch.randn(1536, generator=g).to(torch.bfloat16).to(DEV)
     outs = []
-    for v in (2, 3, 4, 5):
+    for v in (2, 3, 5):
         _hip.set_gemm_variant(v)
         outs.append(_hip.op_linear(x, w, b, act=1, family=_hip.FAMILY_MFMA).clone())
     _hip.set_gemm_variant(0)
@@ -120,7 +119,7 @@ def test_gemm_persistent_matches_one_tile_kernel(built_lib, dtype, epi):
     """>= 512 whole tiles: the throughput schedule runs its persistent kernel; every epilogue must equal the
     one-tile-per-workgroup launch bit for bit."""
     from vall_e.vall_e import _hip
-    M, N, K, T = 40 * 128, 13 * 128, 512, 512
+    M, N, K, T = 40 * 128, 14 * 128, 512, 512
     g = torch.Generator(device="cpu").manual_seed(5)
     x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype).to(DEV)
@@ -129,12 +128,12 @@ def test_gemm_persistent_matches_one_tile_kernel(built_lib, dtype, epi):
     r2 = torch.randn(M, N, generator=g).to(dtype).to(DEV) if epi == "r1r2" else None
     mask = (torch.rand(T, generator=g) < 0.8).to(torch.uint8).to(DEV) if epi == "r1mask" else None
     outs = []
-    for v in (5, 2, 0):
+    for v in (5, 2, 0, 3):
         _hip.set_gemm_variant(v)
         outs.append(_hip.op_linear(x, w, b, act=1 if epi == "gelu" else 0, r1=r1, r2=r2, row_mask=mask, mask_period=T,
                                    family=_hip.FAMILY_MFMA).clone())
     _hip.set_gemm_variant(0)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
     ref = x.float() @ w.float().T + (b.float() if b is not None else 0)
     if epi == "bias" or epi == "nobias":
         assert_close_lp(outs[1], ref, dtype, f"persistent {epi}")

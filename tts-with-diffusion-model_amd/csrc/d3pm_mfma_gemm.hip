@@ -13,20 +13,32 @@
 //     (checked exhaustively against the gfx950 lane groups; SQ_LDS_BANK_CONFLICT = 0 in profiles/);
 //   * v_mfma_f32_16x16x32_{f16,bf16}: each wave owns 64 x 64 = 4 x 4 tiles, fp32 accumulators;
 //   * the MFMA is issued as D = W_frag . X_frag^T so that a lane ends up with 4 consecutive output
-//     columns of one row: bias / GELU / residual / mask run on registers and the store (and the
-//     residual loads) are 8 B per lane; epilogue rounding points are the eager model's (d3pm_kernels.h);
+//     columns of one row; the epilogue regroups them to 8 per lane (v_permlane16_swap) so that bias /
+//     GELU / residual / mask run on registers and residual loads and stores are 16 B per lane;
+//     epilogue rounding points are the eager model's (d3pm_kernels.h);
 //   * tiles are walked in an XCD-aware order (the n-tiles of one X panel share an L2).
-// Two schedules of the same arithmetic (bit-identical results):
-//   throughput (default): ONE 32-KiB LDS stage, two barriers per K-step, FOUR workgroups per CU hide each
-//       other's DMA latency -- 660 / 410 / 530 / 840 / 650 TFLOP/s on the qkv / proj / fc1 / fc2 / final shapes
-//       at M = 24576 (profiles/round1_*_microbench.txt);
+// Three schedules of the same arithmetic (bit-identical results):
+//   throughput, persistent (default for shapes of whole tiles, >= 512 tiles): ONE 32-KiB LDS stage, FOUR
+//       workgroups per CU hide each other's DMA latency, each walks the tiles of its XCD with the next tile's
+//       first k-step in flight under the epilogue -- 845 / 555 / 700 / 950 TFLOP/s on the qkv / proj / fc1+GELU /
+//       fc2 shapes at M = 24576 (profiles/round1_h_microbench.txt);
+//   throughput, one tile per workgroup (ragged shapes such as the 1025-class final layer, 720 TFLOP/s);
 //   latency (M <= 1536, one or two utterances): two stages, the next K-tile's DMA issued from inline asm so
 //       that it stays in flight under the MFMAs (hipcc otherwise drains it before the first ds_read),
 //       counted vmcnt + raw s_barrier; ~10 % shorter kernels when a CU holds a single workgroup.
+// What bounds them (ablation builds, 24576 x 1536 x 512 bf16): main loop alone 36.5 us, the 75 MB of stores alone
+// 13.5 us, the kernel 45 us -- loads (604 MB of L2 -> LDS, 64 flop per byte at 128 x 128) and stores queue on the
+// same CU <-> L2 path, so they add; staggering the co-resident workgroups changes nothing in steady state.
 // Measured and rejected in round 1 (same tests, same shapes; numbers in DESIGN.md §3): register staging
 // (scratch spills, 200 TF/s), 256x128 / 256x256 tiles with 8 / 16 waves (480-530), 256x256 two-stage prefetch
 // (450), K-step 32 two-stage prefetch at 4 workgroups per CU (550), 128x64 tiles at 6 per CU (550),
-// K split four ways inside a 16-wave workgroup for M = 768 (slower: the fixed per-kernel cost dominates).
+// K split four ways inside a 16-wave workgroup for M = 768 (slower: the fixed per-kernel cost dominates),
+// an X-stationary schedule for K = 512 (X fragments resident in 128 VGPRs, W streamed through a 2 x 64 KiB ring,
+// one 8-wave workgroup per CU: correct, 580 vs 845 TF/s -- prologue, DMA issue, epilogue and MFMA phases of the
+// single workgroup run back to back), a persistent 256 x 256 x 64 tile with eight waves and two 64-KiB stages
+// (half the L2 bytes, correct, 583 vs 845 TF/s: 2.25 tiles per CU round up to 3 and the 128-KiB store tail of a
+// tile is not overlapped), 8-row x 128-byte store regrouping by DPP (no change: the store path is not
+// segment-bound).
 // M and N tails are handled by clamped loads and predicated stores; K must be a multiple of 64.
 #include "d3pm_kernels.h"
 
@@ -543,124 +555,6 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128_persist(const T* __restr
 }
 
 
-// ---- X-stationary schedule for K = 512 (d_model of the bench shape): gemm_mfma_xstat ----------------------------
-// PMC says the 128 x 128 schedules are bound by feeding LDS: every workgroup re-stages the same X panel once per
-// n-tile and 42 % of the wave cycles wait on DMA + barriers.  Here a workgroup of 8 waves owns 256 rows of X for
-// its whole life: each wave keeps its 32 rows x 512 k as MFMA fragments in 128 VGPRs (loaded once), and only W
-// is streamed -- 64-row tiles of 64 KiB through a two-slot LDS ring filled by asm-issued global_load_lds (one
-// 1-KiB row per wave-instruction, chunk index XOR-ed with row & 15 on the source address: conflict-free
-// ds_read_b128 of the fragments), next tile in flight under the 128 MFMAs per wave of the current one.
-// L2 -> LDS bytes per flop drop ~4x; two waves per SIMD let one wave's epilogue hide under the other's MFMAs.
-// Arithmetic per output element is identical to the other schedules (k ascending), results are bit-identical.
-constexpr int XS_ROWS = 256, XS_NT = 64, XS_K = 512, XS_SLOT = XS_NT * XS_K * 2;   // 64 KiB per ring slot
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_mfma_xstat(const T* __restrict__ X, int ldx, const T* __restrict__ W,
-                                                          const T* __restrict__ bias, T* Y, int ldy, const T* R1,
-                                                          const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                                          int mask_period, int M, int N, int tiles_per_wg, int n_slices) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q = lane & 15, g = lane >> 4;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int slice = bid % n_slices, m0 = (bid / n_slices) * XS_ROWS;
-  const int n_tiles_total = (N + XS_NT - 1) / XS_NT;
-  const int tile0 = slice * tiles_per_wg;
-  const int n_my = min(tiles_per_wg, n_tiles_total - tile0);
-  if (n_my <= 0) return;                                          // block-uniform
-  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
-
-  // W ring: wave fills rows i*8 + wave (i = 0..7) of each 64-row tile, one row = 1 KiB = one DMA instruction.  The
-  // swizzle key of a row is r & 15 = (i & 1) * 8 + wave: two per-lane source offsets cover all eight instructions.
-  const int key0 = lane ^ wave, key1 = lane ^ (wave + 8);
-  auto issue = [&](int j, int slot) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = i * 8 + wave;
-      int n = (tile0 + j) * XS_NT + r;
-      n = n < N ? n : N - 1;
-      glds16_asm(W + static_cast<size_t>(n) * XS_K + (((i & 1) ? key1 : key0) << 3), lds_base + slot * XS_SLOT + r * 1024);
-    }
-  };
-  // fragment read offsets: row nt*16 + q, chunk (4*ks + g) ^ q  -> lane part for ks & 3, immediates for the rest
-  int xoff[4];
-#pragma unroll
-  for (int k4 = 0; k4 < 4; ++k4) xoff[k4] = q * 1024 + (((4 * k4 + g) ^ q) << 4);
-
-  floatx4 acc[4][2];
-  issue(0, 0);                                             // first W tile on its way while X is fetched
-  // resident X fragments (B operand of D = W_frag . X_frag^T): rows m0 + 32*wave + 16*mt + q, k = 32*ks + 8*g ..
-  uint4 xa[2][16];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    int row = m0 + wave * 32 + mt * 16 + q;
-    row = row < M ? row : M - 1;
-    const T* xr = X + static_cast<size_t>(row) * ldx + g * 8;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) xa[mt][ks] = *reinterpret_cast<const uint4*>(xr + ks * 32);
-  }
-
-  // pin every X fragment as "used" here: hipcc then waits for these loads once, before the loop, instead of
-  // re-executing counted vmcnt waits inside it (which would also drain the W tile kept in flight)
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      asm volatile("" : "+v"(xa[mt][ks].x), "+v"(xa[mt][ks].y), "+v"(xa[mt][ks].z), "+v"(xa[mt][ks].w));
-  for (int j = 0; j < n_my; ++j) {
-    if (j + 1 < n_my) {
-      issue(j + 1, (j + 1) & 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // everything older than the 8 DMAs just issued has landed
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                          // all eight waves' rows of tile j are in LDS
-    __builtin_amdgcn_sched_barrier(0);
-    // the previous tile's epilogue runs HERE, not right after its MFMAs: its stores then have the whole MFMA phase
-    // of tile j to retire before the next counted vmcnt (gfx950 counts stores in vmcnt)
-    if (j > 0)
-      epilogue_store<T, EPI, 4, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wave * 32,
-                                   (tile0 + j - 1) * XS_NT, lane);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const char* slot = smem + (j & 1) * XS_SLOT;
-    // W fragments are double-buffered by hand (fw[ks & 1]): left to itself hipcc funnels all 64 LDS reads of a tile
-    // through one register quad with lgkmcnt(0) before every MFMA pair, i.e. fully exposed LDS latency
-    uint4 fw[2][4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) fw[0][nt] = *reinterpret_cast<const uint4*>(slot + nt * 16384 + xoff[0]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);         // k-step 0's reads lead the pipeline
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      if (ks + 1 < 16) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          fw[(ks + 1) & 1][nt] =
-              *reinterpret_cast<const uint4*>(slot + nt * 16384 + xoff[(ks + 1) & 3] + ((ks + 1) >> 2) * 256);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mma<T>(fw[ks & 1][nt], xa[mt][ks], acc[nt][mt]);
-      if (ks + 1 < 16) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read of the next k-step ...
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // ... under two MFMAs of this one
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // slot j&1 may be refilled (by issue(j+2) next iteration)
-  }
-  epilogue_store<T, EPI, 4, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wave * 32,
-                               (tile0 + n_my - 1) * XS_NT, lane);
-}
-
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -681,90 +575,46 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
-static int g_gemm_variant = 0;   // 0 auto, 2 throughput (persistent over whole tiles), 3 latency, 4 X-stationary (K = 512 only), 5 throughput with one tile per workgroup
+static int g_gemm_variant = 0;       // 0 auto, 2 throughput (persistent over whole tiles), 3 latency, 5 throughput with one tile per workgroup
 static int g_persist_slots = 1024;   // resident workgroups of the persistent schedule: 4 per CU x 256 CUs
-static bool g_xstat_auto = false;   // flipped to true once measured faster (D3PM_TUNE_GEMM_VARIANT 4 forces it)
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_gemm_persist_slots(int v) { g_persist_slots = v; }
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
-  // Both schedules accumulate in the same order, so the choice never changes a bit of the result.
+  // All schedules accumulate in the same order, so the choice never changes a bit of the result.
   const bool ffn_act = a.act == ACT_RELU || a.act == ACT_SILU;
-  const bool xstat = a.K == XS_K && !ffn_act && (g_gemm_variant == 4 || (g_gemm_variant == 0 && g_xstat_auto && a.M >= 4096));
-  const bool latency = !xstat && !ffn_act && (g_gemm_variant == 3 || (g_gemm_variant == 0 && a.M <= 1536));
-  int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
+  const bool latency = !ffn_act && (g_gemm_variant == 3 || (g_gemm_variant == 0 && a.M <= 1536));
+  const int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
   // shapes made of whole tiles go through the persistent kernel once there are enough tiles to fill the chip twice
   // over (a ragged edge would need a second launch that costs more than persistence gains: measured on N = 1025)
-  const int n_full = a.N / BN, m_full = a.M / BM;
-  const bool persist = !xstat && !latency && !ffn_act && (g_gemm_variant == 0 || g_gemm_variant == 2) &&
-                       a.M % BM == 0 && a.N % BN == 0 && static_cast<long long>(n_full) * m_full >= 2 * 256 &&
+  const bool persist = !latency && !ffn_act && (g_gemm_variant == 0 || g_gemm_variant == 2) && a.M % BM == 0 &&
+                       a.N % BN == 0 && static_cast<long long>(n_tiles) * m_tiles >= 2 * 256 &&
                        static_cast<long long>(BM) * a.ldx * 2 < (1ll << 31) && static_cast<long long>(BN) * a.K * 2 < (1ll << 31);
-  size_t lds = (latency ? 4 : 2) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
-  dim3 grid(static_cast<unsigned>(n_tiles) * m_tiles), block(256);
-  int xs_tiles_per_wg = 0, xs_slices = 1;
-  if (xstat) {
-    // one workgroup (8 waves, 256 rows) per CU: split N into as many slices as keep <= 256 workgroups in flight
-    m_tiles = (a.M + XS_ROWS - 1) / XS_ROWS;
-    const int nt64 = (a.N + XS_NT - 1) / XS_NT;
-    xs_slices = 256 / m_tiles;
-    xs_slices = xs_slices < 1 ? 1 : (xs_slices > nt64 ? nt64 : xs_slices);
-    xs_tiles_per_wg = (nt64 + xs_slices - 1) / xs_slices;
-    xs_slices = (nt64 + xs_tiles_per_wg - 1) / xs_tiles_per_wg;
-    grid = dim3(static_cast<unsigned>(m_tiles) * xs_slices);
-    block = dim3(512);
-    lds = 2 * XS_SLOT;
-  }
+  const size_t lds = (latency ? 4 : 2) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
+  const int tiles_total = n_tiles * m_tiles, want = (tiles_total + 7) & ~7;
+  const dim3 grid(static_cast<unsigned>(persist ? (want < g_persist_slots ? want : g_persist_slots) : tiles_total)), block(256);
   const int epi = (a.act == ACT_GELU ? EPI_GELU : a.act == ACT_RELU ? EPI_RELU : a.act == ACT_SILU ? EPI_SILU : 0) |
                   (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
 
-#define D3PM_GEMM(...)                                                                                          \
+#define D3PM_GEMM(KERNEL, ...)                                                                                  \
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),                           \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XS_SLOT));             \
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),                                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));          \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    __VA_ARGS__<<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),        \
-                                         static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,            \
-                                         static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr,       \
-                                         a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles);                    \
+    KERNEL<<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),             \
+                                    static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,                 \
+                                    static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr, a.row_mask, \
+                                    a.mask_period, a.M, a.N, a.K, n_tiles, ##__VA_ARGS__);                      \
     return D3PM_OK;                                                                                             \
   } while (0)
-#define D3PM_GEMM_XS(...)                                                                                       \
-  do {                                                                                                          \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&__VA_ARGS__),                           \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XS_SLOT));             \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
-    __VA_ARGS__<<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),        \
-                                         static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,            \
-                                         static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr,       \
-                                         a.row_mask, a.mask_period, a.M, a.N, xs_tiles_per_wg, xs_slices);      \
-    return D3PM_OK;                                                                                             \
-  } while (0)
-#define D3PM_GEMM_PERSIST(E)                                                                                    \
-  do {                                                                                                          \
-    const int want = (m_full * n_full + 7) & ~7;                                                                \
-    const dim3 pgrid(static_cast<unsigned>(want < g_persist_slots ? want : g_persist_slots));                   \
-    const U* X = static_cast<const U*>(a.X);                                                                    \
-    const U* Wp = static_cast<const U*>(a.W);                                                                   \
-    const U* bp = static_cast<const U*>(a.bias);                                                                \
-    U* Yp = static_cast<U*>(a.Y);                                                                               \
-    const U* r1 = static_cast<const U*>(a.R1);                                                                  \
-    const U* r2 = static_cast<const U*>(a.R2);                                                                  \
-    gemm_mfma_128_persist<U, E><<<pgrid, block, lds, s>>>(X, a.ldx, Wp, bp, Yp, a.ldy, r1, r2, a.ldr, a.row_mask, \
-                                                          a.mask_period, a.M, a.N, a.K, n_full, m_full * n_full); \
-    return D3PM_OK;                                                                                             \
-  } while (0)
-#define D3PM_GEMM_EPI(E)                                  \
-  do {                                                    \
-    if (xstat) D3PM_GEMM_XS(gemm_mfma_xstat<U, E>);       \
-    else if (latency) D3PM_GEMM(gemm_mfma_128_pf<U, E>);  \
-    else if (persist) D3PM_GEMM_PERSIST(E);               \
-    else D3PM_GEMM(gemm_mfma_128_glds<U, E>);             \
+#define D3PM_GEMM_EPI(E)                                                \
+  do {                                                                  \
+    if (latency) D3PM_GEMM((gemm_mfma_128_pf<U, E>));                   \
+    else if (persist) D3PM_GEMM((gemm_mfma_128_persist<U, E>), tiles_total); \
+    else D3PM_GEMM((gemm_mfma_128_glds<U, E>));                         \
   } while (0)
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
@@ -774,15 +624,13 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
       case EPI_R1: D3PM_GEMM_EPI(EPI_R1);
       case EPI_R2: D3PM_GEMM_EPI(EPI_R2);
       case EPI_R1 | EPI_MASK: D3PM_GEMM_EPI(EPI_R1 | EPI_MASK);
-      case EPI_RELU: D3PM_GEMM(gemm_mfma_128_glds<U, EPI_RELU>);
-      case EPI_SILU: D3PM_GEMM(gemm_mfma_128_glds<U, EPI_SILU>);
+      case EPI_RELU: D3PM_GEMM((gemm_mfma_128_glds<U, EPI_RELU>));
+      case EPI_SILU: D3PM_GEMM((gemm_mfma_128_glds<U, EPI_SILU>));
       default: break;
     }
     return D3PM_E_SHAPE;
   };
 #undef D3PM_GEMM_EPI
-#undef D3PM_GEMM_PERSIST
-#undef D3PM_GEMM_XS
   int rc = dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
   if (rc != D3PM_OK) return rc;
 #undef D3PM_GEMM
