@@ -76,3 +76,29 @@ def test_nar_mfma_family_and_batch_independence(built_lib):
     for b in range(3):
         one = m([texts[b]], [proms[b]], [resps[b]], seed=3, utt0=b)
         assert (one[0] == batch[b]).float().mean().item() > 0.98
+
+
+def test_cli_two_stages_write_a_qnt_file(built_lib, tmp_path):
+    """`python -m vall_e` with pre-tokenised inputs (formats.py): D3PM stage -> NAR stage -> `.qnt.pt` [1, 8, t] in the
+    layout EnCodec's decoder reads (/root/reference/vall_e/__main__.py:44-73, emb/qnt.py:68,93)."""
+    import json
+    from vall_e import __main__ as cli, formats
+    (tmp_path / "u.phn.txt").write_text("HH AH0 L OW1 _ W ER1 L D", encoding="utf8")
+    symmap = formats.build_symmap([formats.read_phones(tmp_path / "u.phn.txt")])
+    (tmp_path / "symmap.json").write_text(json.dumps(symmap), encoding="utf8")
+    torch.save(torch.randint(0, 1024, (1, 8, 120), dtype=torch.int64), tmp_path / "prompt.qnt.pt")
+    argv = [str(tmp_path / "out.qnt.pt"), "--phn-file", str(tmp_path / "u.phn.txt"), "--symmap", str(tmp_path / "symmap.json"),
+            "--prompt-qnt", str(tmp_path / "prompt.qnt.pt"), "--native", "--seed", "5", "--nar-model", "nar-quarter"]
+    torch.manual_seed(0)
+    cli.main(argv)                                                   # level 0 only: no --nar-ckpt
+    lvl0 = torch.load(tmp_path / "out.qnt.pt")
+    assert lvl0.shape == (1, 1, 350) and lvl0.dtype == torch.int64 and 0 <= lvl0.min() and lvl0.max() <= 1024
+    from vall_e.vall_e import get_model
+    torch.manual_seed(1)
+    torch.save(get_model("nar-quarter").state_dict(), tmp_path / "nar.pt")
+    torch.manual_seed(0)
+    cli.main(argv + ["--nar-ckpt", str(tmp_path / "nar.pt")])
+    full = torch.load(tmp_path / "out.qnt.pt")
+    assert full.shape == (1, 8, 350) and full.dtype == torch.int64
+    assert torch.equal(full[:, :1], lvl0)                             # the NAR stage keeps level 0
+    assert 0 <= full[:, 1:].min() and full[:, 1:].max() < 1024

@@ -1,15 +1,18 @@
 """`python -m vall_e` -- caller of the D3PM sampler with the reference CLI's shape
-(/root/reference/vall_e/__main__.py:44-73: TEXT REFERENCE OUT [--ar-ckpt] [--device]).
+(/root/reference/vall_e/__main__.py:44-73: TEXT REFERENCE OUT [--ar-ckpt] [--nar-ckpt] [--device]).
 
 The reference front-ends are third-party and need downloads (g2p_en for phonemes, EnCodec for the prompt and for
-decoding) and its second stage is the stock NAR model; none of them is part of this build.  This
-entry point therefore takes what those front-ends would produce and writes what the NAR stage would consume:
+decoding); they are not part of this build.  This entry point takes what those front-ends write
+(formats.py) and writes what EnCodec's decoder reads:
 
-    python -m vall_e --phonemes "12 7 33 4" --prompt-qnt prompt.qnt.pt --ar-ckpt ar_state_dict.pt out_codes.pt
+    python -m vall_e --phn-file utt.phn.txt --symmap symmap.json --prompt-qnt prompt.qnt.pt \
+                     --ar-ckpt ar_state_dict.pt --nar-ckpt nar_state_dict.pt out.qnt.pt
 
-  --phonemes    space-separated phoneme ids (the reference maps g2p symbols through ar.phone_symmap, 1-based)
+  --phonemes    space-separated phoneme ids, or
+  --phn-file    a `.phn.txt` file of phone symbols (+ --symmap, the JSON export of `ar.phone_symmap`)
   --prompt-qnt  a `.qnt.pt` file as written by the reference's emb/qnt.py:68,93 (int64 [1, 8, t])
-  out           torch.save of the level-0 codes, int64 [n_frames] (trimmed) -- `resps_list=[codes.unsqueeze(-1)]`
+  --nar-ckpt    state_dict of the stock NAR model: levels 1..7 are filled in and `out` is a `.qnt.pt` [1, 8, t];
+                without it `out` holds the level-0 codes only ([1, 1, t])
 """
 import argparse
 from pathlib import Path
@@ -17,28 +20,48 @@ from pathlib import Path
 import torch
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser("D3PM codec-token sampler (MI355X)")
     ap.add_argument("out_path", type=Path)
-    ap.add_argument("--phonemes", required=True)
+    ap.add_argument("--phonemes", default=None)
+    ap.add_argument("--phn-file", type=Path, default=None)
+    ap.add_argument("--symmap", type=Path, default=None)
     ap.add_argument("--prompt-qnt", type=Path, required=True)
     ap.add_argument("--ar-ckpt", type=Path, default=None, help="state_dict in the reference key layout (random init if absent)")
+    ap.add_argument("--nar-ckpt", type=Path, default=None, help="state_dict of the NAR model (vall_e/vall_e/nar.py)")
+    ap.add_argument("--nar-model", default="nar", help="registry name of the NAR model: nar, nar-half, nar-quarter")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16", "float32"])
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--native", action="store_true", help="the shape upstream's class really builds (d=32, 16 heads, 8 blocks)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
+    from . import formats
     from .vall_e import AR, get_model
+    if (args.phonemes is None) == (args.phn_file is None):
+        ap.error("give exactly one of --phonemes / --phn-file")
+    if args.phn_file is not None:
+        if args.symmap is None:
+            ap.error("--phn-file needs --symmap")
+        phns = formats.phones_to_ids(formats.read_phones(args.phn_file), formats.load_symmap(args.symmap))
+    else:
+        phns = torch.tensor([int(p) for p in args.phonemes.split()], dtype=torch.long)
+    proms = formats.load_quants(args.prompt_qnt)                                   # (t, 8) like data.py:31-37
+
+    dtype = getattr(torch, args.dtype)
     model = AR.reference_native().to(args.device) if args.native else get_model("diffusion")
     if args.ar_ckpt is not None:
         model.load_state_dict(torch.load(args.ar_ckpt, map_location="cpu"))
-    model = model.to(getattr(torch, args.dtype)).to(args.device)
-    phns = torch.tensor([int(p) for p in args.phonemes.split()], dtype=torch.long)
-    qnt = torch.load(args.prompt_qnt, map_location="cpu")
-    proms = qnt[0].t().contiguous().long() if qnt.dim() == 3 else qnt.long()       # (t, 8) like data.py:31-37
+    model = model.to(dtype).to(args.device)
     codes = model.generate_audio(text_list=[phns], proms_list=[proms], seed=args.seed)
-    torch.save(codes[: model.cfg.n_frames].cpu(), args.out_path)
+    resps = codes[: model.cfg.n_frames].unsqueeze(-1)                              # __main__.py:64 of the reference
+    if args.nar_ckpt is not None:
+        nar = get_model(args.nar_model)
+        nar.load_state_dict(torch.load(args.nar_ckpt, map_location="cpu"))
+        nar = nar.to(dtype).to(args.device)
+        resps = nar(text_list=[phns.to(args.device)], proms_list=[proms.to(args.device)], resps_list=[resps],
+                    seed=args.seed)[0]
+    formats.save_quants(resps, args.out_path)
     print(args.out_path, "saved.")
 
 
