@@ -44,7 +44,10 @@ enum {
 /* flags for d3pm_sample_loop / d3pm_denoise_step */
 enum {
   D3PM_FLAG_GREEDY = 1,        /* argmax of the posterior without Gumbel noise   */
-  D3PM_FLAG_FORCE_GENERIC = 2  /* never take the MFMA kernels (cross-check / debugging)          */
+  D3PM_FLAG_FORCE_GENERIC = 2, /* never take the MFMA kernels (cross-check / debugging)          */
+  D3PM_FLAG_SEED_IN_HBM = 4    /* d3pm_sample_loop: `seed` is the address of a uint64 in HBM, read by the sampling
+                                  kernel at run time -- a captured HIP graph of the loop can then be replayed with a
+                                  new seed (measured: no faster than eager launches, 66.6 vs 66.3 ms per utterance) */
 };
 
 typedef struct d3pm_shape {

@@ -434,3 +434,19 @@ def test_sample_loop_is_hip_graph_capturable(n16):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(x_graph, x_eager)
+
+
+def test_generate_audio_graph_replay_equals_eager_launches(n16):
+    """generate_audio(graph=True) replays the loop from a HIP graph whose seed lives in HBM (D3PM_FLAG_SEED_IN_HBM):
+    same ids as the eager launches, for every seed, from ONE captured graph."""
+    m = n16.model
+    texts, proms = n16.texts[:1], n16.proms[:1]
+    outs, n_graphs = {}, None
+    for seed in (3, 4, 3):
+        eager = m.generate_audio(texts, proms, steps=12, seed=seed, graph=False)
+        graphed = m.generate_audio(texts, proms, steps=12, seed=seed, graph=True)
+        assert torch.equal(eager, graphed), seed
+        outs.setdefault(seed, graphed)
+        n_graphs = n_graphs or len(m.sampler()._graphs)
+    assert not torch.equal(outs[3], outs[4])
+    assert len(m.sampler()._graphs) == n_graphs                      # new seeds did not capture new graphs

@@ -422,6 +422,7 @@ int d3pm_sample_loop(const d3pm_shape* sh, const d3pm_weights* w, int batch, int
     a.logits = ws.logits; a.logits_dtype = sh->dtype; a.ldl = logits_ld(*sh); a.x_t = x; a.x_next = x;
     a.x_next2 = trace ? trace + static_cast<size_t>(t_start - t) * rows : nullptr;
     a.rows = rows; a.n_classes = sh->n_classes; a.mask_id = sh->mask_id; a.canvas = sh->canvas; a.seed = seed;
+    if (flags & D3PM_FLAG_SEED_IN_HBM) a.seed_hbm = reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(seed));
     a.row0 = utt0 * static_cast<uint32_t>(sh->canvas); a.greedy = (flags & D3PM_FLAG_GREEDY) ? 1 : 0;
     a.pc = make_posterior_consts(sched, t);
     {

@@ -74,6 +74,7 @@ struct SampleArgs {
   uint16_t* posterior_out = nullptr;
   int rows = 0, n_classes = 0, mask_id = 0, canvas = 0;
   uint64_t seed = 0; uint32_t row0 = 0; int greedy = 0;
+  const uint64_t* seed_hbm = nullptr;   // when set, the kernel reads the seed from HBM (lets a captured HIP graph be replayed with a new seed)
   PosteriorConsts pc{};
 };
 

@@ -35,10 +35,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void posterior_sample_rows(
     const T* __restrict__ logits, int ldl, const int32_t* x_t, int32_t* x_next,
     int32_t* x_next2, uint16_t* __restrict__ post_out, int rows, int K, int mask_id,
-    uint64_t seed, uint32_t row0, int greedy, PosteriorConsts pc) {
+    uint64_t seed, const uint64_t* __restrict__ seed_hbm, uint32_t row0, int greedy, PosteriorConsts pc) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + wave;
   if (row >= rows) return;
+  if (seed_hbm) seed = *seed_hbm;
   const T* lr = logits + static_cast<size_t>(row) * ldl;
   const int groups = (K + 3) >> 2;
   float z[kMaxGroupsPerLane][4];
@@ -178,7 +179,7 @@ int posterior_sample(const SampleArgs& a, hipStream_t s) {
 #define D3PM_PS(T)                                                                                      \
   posterior_sample_rows<T><<<grid, block, 0, s>>>(static_cast<const T*>(a.logits), a.ldl, a.x_t, a.x_next, \
                                                   a.x_next2, a.posterior_out, a.rows, a.n_classes,        \
-                                                  a.mask_id, a.seed, a.row0, a.greedy, a.pc)
+                                                  a.mask_id, a.seed, a.seed_hbm, a.row0, a.greedy, a.pc)
   switch (a.logits_dtype) {
     case D3PM_F32: D3PM_PS(float); break;
     case D3PM_F16: D3PM_PS(f16); break;

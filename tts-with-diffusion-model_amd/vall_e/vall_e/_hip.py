@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 F32, F16, BF16 = 0, 1, 2
-FLAG_GREEDY, FLAG_FORCE_GENERIC = 1, 2
+FLAG_GREEDY, FLAG_FORCE_GENERIC, FLAG_SEED_IN_HBM = 1, 2, 4
 K_GEMM, K_ATTN, K_SAMPLE, K_LN = 0, 1, 2, 3
 
 _DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -261,6 +261,7 @@ class Sampler:
         self._cond_ws = None
         self.schedule = Schedule(cfg.timesteps)
         self._ws = {}
+        self._graphs = {}
         self.film = torch.empty((cfg.timesteps + 1, cfg.n_layers, 2 * cfg.d_model), dtype=dtype, device=self.device)
         check(lib().d3pm_film_table(C.byref(self.shape), C.byref(self.weights.c_struct), _p(self.film), stream_ptr()),
               "d3pm_film_table")
@@ -334,6 +335,40 @@ class Sampler:
                                      C.byref(self.schedule.c_struct), seed, utt0, flags, _p(ws), ws.numel(), _p(tr),
                                      stream_ptr()), "d3pm_sample_loop")
         return tr
+
+    def sample_loop_graphed(self, x, frame_mask, t_start, t_stop, kv_t, kv_p, seed, utt0=0, flags=0):
+        """The same loop replayed from a captured HIP graph: one launch instead of ~50 per iteration, for the
+        launch-bound regime (one or two utterances).  The graph is captured once per (batch, step range, utt0,
+        flags) over static buffers; the seed lives in HBM (D3PM_FLAG_SEED_IN_HBM) so that a replay can draw new
+        noise.  `x` is updated in place like sample_loop does."""
+        B = x.shape[0]
+        key = (B, int(t_start), int(t_stop), int(utt0), int(flags))
+        ent = self._graphs.get(key)
+        if ent is None:
+            st = {"x": torch.empty_like(x), "mask": torch.empty_like(frame_mask), "kv_t": torch.empty_like(kv_t),
+                  "kv_p": torch.empty_like(kv_p), "seed": torch.zeros(1, dtype=torch.int64, device=self.device)}
+            for k, v in (("x", x), ("mask", frame_mask), ("kv_t", kv_t), ("kv_p", kv_p)):
+                st[k].copy_(v)
+            fl = int(flags) | FLAG_SEED_IN_HBM
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):          # eager warm-up on the capture stream: lazy module load, func attributes
+                self.sample_loop(st["x"], st["mask"], t_start, max(t_start - 1, t_stop), st["kv_t"], st["kv_p"],
+                                 st["seed"].data_ptr(), utt0=utt0, flags=fl, slot=("graph",) + key)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.sample_loop(st["x"], st["mask"], t_start, t_stop, st["kv_t"], st["kv_p"], st["seed"].data_ptr(),
+                                 utt0=utt0, flags=fl, slot=("graph",) + key)
+            ent = self._graphs[key] = (graph, st)
+        graph, st = ent
+        st["x"].copy_(x)
+        st["mask"].copy_(frame_mask)
+        st["kv_t"].copy_(kv_t)
+        st["kv_p"].copy_(kv_p)
+        st["seed"].fill_(int(seed))
+        graph.replay()
+        x.copy_(st["x"])
 
     def q_sample(self, x0, frame_mask, t, seed, utt0=0):
         out = torch.empty_like(x0)
@@ -438,8 +473,13 @@ def set_gemm_persist_slots(v: int):
     check(lib().d3pm_set_tuning(2, v), "d3pm_set_tuning")
 
 
+_PROFILING = False
+
+
 def prof_enable(kclass: int, max_events: int):
+    global _PROFILING
     check(lib().d3pm_prof_enable(kclass, max_events), "d3pm_prof_enable")
+    _PROFILING = True
 
 
 def prof_read():
@@ -449,4 +489,10 @@ def prof_read():
 
 
 def prof_disable():
+    global _PROFILING
     lib().d3pm_prof_disable()
+    _PROFILING = False
+
+
+def profiling() -> bool:
+    return _PROFILING
