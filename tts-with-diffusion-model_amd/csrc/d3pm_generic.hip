@@ -132,6 +132,8 @@ __global__ __launch_bounds__(256) void linear_tiled(const T* __restrict__ X, int
 // one wave per query row, lanes over keys for the scores / softmax, lanes over (column, key
 // group) for P.V.  Scores, normalised probabilities and the output are rounded to the storage
 // dtype like the eager bmm/softmax/bmm chain.  LDS: per wave [S] floats + [hd] floats.
+template <typename T> struct alignas(16) Vec16 { T v[16 / sizeof(T)]; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void attention_rows(const T* __restrict__ Q, int ldq,
                                                       const T* __restrict__ Kp,
@@ -149,6 +151,8 @@ __global__ __launch_bounds__(256) void attention_rows(const T* __restrict__ Q, i
   const int G = kWave / hdp;                      // key groups per pass
   const T* Kb = Kp + static_cast<size_t>(b) * S_pad * ldkv + h * hd;
   const T* Vb = Vp + static_cast<size_t>(b) * S_pad * ldkv + h * hd;
+  constexpr int VEC = 16 / static_cast<int>(sizeof(T));
+  const bool vec_ok = hd % VEC == 0 && ldkv % VEC == 0 && (reinterpret_cast<uintptr_t>(Kp) & 15) == 0;   // block-uniform
   for (int qi = 0; qi < q_per_wave; ++qi) {
     const int i = (blockIdx.x * nw + wave) * q_per_wave + qi;
     const bool active = i < Tq;                    // wave-uniform; barriers stay block-uniform
@@ -161,7 +165,15 @@ __global__ __launch_bounds__(256) void attention_rows(const T* __restrict__ Q, i
       for (int j = lane; j < S; j += kWave) {
         const T* kr = Kb + static_cast<size_t>(j) * ldkv;
         float s = 0.f;
-        for (int c = 0; c < hd; ++c) s = fmaf(qs[c], ldf(kr + c), s);
+        if (vec_ok) {   // same FMA chain in the same order, the key row just arrives 16 bytes at a time
+          for (int c = 0; c < hd; c += VEC) {
+            const Vec16<T> kv = *reinterpret_cast<const Vec16<T>*>(kr + c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s = fmaf(qs[c + e], static_cast<float>(kv.v[e]), s);
+          }
+        } else {
+          for (int c = 0; c < hd; ++c) s = fmaf(qs[c], ldf(kr + c), s);
+        }
         s = rn<T>(s);
         sc[j] = s;
         mx = fmaxf(mx, s);
