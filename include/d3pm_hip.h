@@ -196,6 +196,15 @@ int d3pm_q_sample(const d3pm_shape *shape, int batch, const int32_t *x0, int32_t
                   const uint8_t *frame_mask, int t, const d3pm_schedule *sched, uint64_t seed,
                   uint32_t utt0, void *stream);
 
+/* Training-side loss of one denoiser evaluation (AR.forward, ar_discrete.py:683-690; SURVEY.md §8f row 3, forward
+ * half): row_loss[b][i] = logsumexp(x) - x[target] with x = logits[b][i][:] * mask[i], target = targets[b][i] (already
+ * multiplied by the mask by the caller), fp32.  A padded frame (mask 0) yields log(n_classes).  logits device
+ * [batch][canvas][n_classes] contiguous in `logits_dtype`; targets device int32 [batch][canvas]; row_loss device fp32
+ * [batch][canvas].  The reference's loss of one step is the mean of these rows; the backward pass is not part of
+ * this library. */
+int d3pm_ce_loss_rows(const d3pm_shape *shape, int batch, const void *logits, int logits_dtype,
+                      const int32_t *targets, const uint8_t *frame_mask, float *row_loss, void *stream);
+
 /* The raw uniform stream the two samplers consume (what the reference draws with torch.rand,
  * ar_discrete.py:402,480): out device fp32 [rows][n_classes] for global rows row0.. at step t. */
 int d3pm_uniform(uint64_t seed, int t, uint32_t row0, int rows, int n_classes, int stream_id,

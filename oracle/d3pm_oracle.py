@@ -293,6 +293,33 @@ def q_sample(x0, t: int, tabs, uniform32, mask, mask_id: int = MASK_ID):
     return gumbel_argmax(logits, uniform32, 1) * mask
 
 
+def pad_canvas(resps, canvas: int):
+    """AR.forward's zero padding / truncation of the target codes to the canvas (ar_discrete.py:591-598)."""
+    r = resps.long()[:canvas]
+    return F.pad(r, (0, canvas - r.shape[0]))
+
+
+def training_forward(sd, shape: Shape, text, prompt, resps, q_noise: Callable[[int], torch.Tensor], timesteps: Optional[int] = None):
+    """The training-side forward of ONE utterance (ar_discrete.py:588-694; the reference indexes `[0]` throughout, so
+    this is what it computes for every batch size): for t = 1 .. timesteps-1
+        x_t = q_sample(x_0, t) * mask, logits = final(blocks(emb(x_t) * mask)) * mask,
+        loss += cross_entropy(logits, x_0 * mask, mean over the canvas)
+    and loss / mask.sum() at the end, mask = (x_0 != 0).  `q_noise(t)` -> fp32 uniforms [canvas, K] (the reference
+    draws torch.rand per step; fixtures use Philox stream 1).  Returns (loss, logits of the last step)."""
+    T = shape.timesteps if timesteps is None else timesteps
+    x0 = pad_canvas(resps, shape.canvas)
+    mask = x0 != 0
+    cp, ct = encode_conditions(sd, shape, text, prompt)
+    tabs = scalar_tables(cosine_betas(shape.timesteps), shape.timesteps)
+    targets = x0 * mask
+    loss, x = 0, None
+    for t in range(1, T):
+        x_t = q_sample(x0, t, tabs, q_noise(t), mask)
+        x = denoiser_logits(sd, shape, x_t, t, cp, ct, mask) * mask[:, None]
+        loss = loss + F.cross_entropy(x, targets, reduction="mean")
+    return loss / mask.sum().item(), x
+
+
 # --------------------------------------------------------------------------------------------
 # Full reverse process
 # --------------------------------------------------------------------------------------------

@@ -24,6 +24,8 @@ Fixtures
 """
 from __future__ import annotations
 
+import contextlib
+import io
 import os
 import platform
 import sys
@@ -285,6 +287,51 @@ def gen_native(out, m):
     np.savez_compressed(os.path.join(out, "native_loop.npz"), **loop)
 
 
+def gen_forward(out, m):
+    """Training-side forward (ar_discrete.py:588-694) of one utterance on the native shape: the reference's own
+    forward() with its q_sample draws replaced by Philox stream 1 (one torch.rand call per step, t = 1..99)."""
+    cfg = synth.D3PMConfig.native()
+    shape = O.Shape.of(cfg)
+    sd32 = synth.make_state_dict(cfg, W_SEED)
+    texts, proms = synth.make_inputs(cfg, 1, IN_SEED)
+    m.float().load_state_dict(sd32)
+    rng = np.random.Generator(np.random.PCG64(77))
+    resps = torch.from_numpy(rng.integers(1, 1024, size=300).astype(np.int64))       # 300 live frames, ids >= 1
+    fw = {"resps": resps.numpy().astype(np.int16), "seed": np.array(31)}
+
+    class QNoise:
+        def __init__(self):
+            self.t = 1
+        def __enter__(self):
+            self.orig = torch.rand
+            def rand(size=None, *a, **k):
+                u = torch.from_numpy(philox.uniform_batch(31, self.t, 0, 1, cfg.canvas, stream=philox.STREAM_Q_SAMPLE))
+                self.t += 1
+                return u
+            torch.rand = rand
+            return self
+        def __exit__(self, *exc):
+            torch.rand = self.orig
+
+    def q_noise(t):
+        return torch.from_numpy(philox.uniform_batch(31, t, 0, 1, cfg.canvas, stream=philox.STREAM_Q_SAMPLE))[0]
+
+    for tag, dtype in (("f32", torch.float32), ("f16", torch.float16)):
+        mm = m.half() if dtype == torch.float16 else m.float()
+        sd = {k: v.to(dtype) for k, v in sd32.items()}
+        with rh.cuda_strings_as_cpu(), QNoise(), torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            x = mm.forward([texts[0]], [proms[0]], [resps])
+        with torch.no_grad():
+            loss_o, x_o = O.training_forward(sd, shape, texts[0], proms[0], resps, q_noise)
+        assert torch.equal(x, x_o), tag
+        assert torch.equal(mm.loss, loss_o.to(mm.loss.dtype)), (tag, mm.loss, loss_o)
+        fw[f"loss_{tag}"] = np.array(float(mm.loss), dtype=np.float64)
+        fw[f"last_logits_rows_{tag}"] = (x[ROWS].numpy() if dtype == torch.float32 else bits16(x[ROWS]))
+        print(f"  forward {tag}: loss {float(mm.loss):.6f}")
+    m.float()
+    np.savez_compressed(os.path.join(out, "native_forward.npz"), **fw)
+
+
 def gen_wide(out, m):
     """Swap the reference's own classes in at d=512,H=8,L=6 (canvas stays the hard-coded 448/350)."""
     base, ard = rh.load_reference_modules()
@@ -405,6 +452,7 @@ def main():
     print("tables ..."); m = gen_tables(out)
     print("tables (200 steps) ..."); gen_tables_t200(out)
     print("native ..."); gen_native(out, m)
+    print("forward ..."); gen_forward(out, m)
     print("wide ...");   gen_wide(out, m)
     print("nar ...");    gen_nar(out)
     with open(os.path.join(out, "FINGERPRINT.txt"), "w") as f:

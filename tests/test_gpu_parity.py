@@ -450,3 +450,28 @@ def test_generate_audio_graph_replay_equals_eager_launches(n16):
         n_graphs = n_graphs or len(m.sampler()._graphs)
     assert not torch.equal(outs[3], outs[4])
     assert len(m.sampler()._graphs) == n_graphs                      # new seeds did not capture new graphs
+
+
+@pytest.mark.parametrize("tag", ["f16", "f32"])
+def test_training_forward_loss_matches_the_reference(tag, n16, n32):
+    """SURVEY §8f row 3, forward half: AR.forward = q_sample (Philox stream 1) -> denoiser -> masked cross-entropy,
+    99 steps, against the loss the reference's own forward() produced on these inputs (tests/golden/native_forward.npz)
+    and against the oracle's last-step logits."""
+    n = n16 if tag == "f16" else n32
+    g = load("native_forward.npz")
+    resps = torch.from_numpy(g["resps"].astype(np.int64))
+    seed = int(g["seed"])
+    last = n.model([n.texts[0]], [n.proms[0]], [resps], seed=seed)
+    loss = float(n.model.loss)
+    ref = float(g[f"loss_{tag}"])
+    REPORT[f"training_forward_loss_{tag}"] = {"hip": loss, "reference": ref}
+    assert abs(loss - ref) < (2e-4 if tag == "f32" else 4e-3), (loss, ref)
+    rows = load("native_step.npz")["rows"]
+    ref_rows = torch.from_numpy(g["last_logits_rows_f32"]) if tag == "f32" else f16(g["last_logits_rows_f16"])
+    got = last[rows].float().cpu()
+    assert last.shape == (n.cfg.canvas, n.cfg.n_classes) and bool((last[300:] == 0).all())
+    # the noised canvas of the last step must be the reference's (integer path), so the logits agree to rounding
+    assert (got - ref_rows.float()).abs().max().item() < (1e-3 if tag == "f32" else 2e-2)
+    # two utterances = two independent single-utterance runs, averaged
+    two = n.model([n.texts[0], n.texts[1]], [n.proms[0], n.proms[1]], [resps, resps[:200]], seed=seed)
+    assert two.shape == last.shape and torch.isfinite(n.model.loss)

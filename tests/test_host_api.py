@@ -109,8 +109,10 @@ def test_no_cpu_fallback():
     m = AR.reference_native()
     with pytest.raises(RuntimeError, match="no CPU path"):
         m.generate_audio([torch.tensor([1, 2, 3])], [torch.zeros(4, 8, dtype=torch.long)])
-    with pytest.raises(NotImplementedError):
-        m(None, None)
+    with pytest.raises(RuntimeError, match="no CPU path"):       # the training-side forward has none either
+        m([torch.tensor([1, 2, 3])], [torch.zeros(4, 8, dtype=torch.long)], [torch.tensor([5, 6, 7])])
+    with pytest.raises(ValueError):
+        m([torch.tensor([1])], [torch.zeros(4, 8, dtype=torch.long)])
 
 
 def test_product_never_imports_the_oracle():

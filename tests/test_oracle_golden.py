@@ -166,3 +166,32 @@ def test_gumbel_max_is_the_categorical_distribution():
     ids = N.sample_gumbel([logits], 1.0, seed=5, level=0)[0]
     freq = torch.bincount(ids, minlength=5).float() / len(ids)
     assert (freq - torch.softmax(logits[0], -1)).abs().max() < 0.012
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("f16", torch.float16)])
+def test_training_forward_loss(tag, dtype):
+    """SURVEY §8f row 3, forward half: the reference's own AR.forward (ar_discrete.py:588-694) ran on these inputs
+    with its q_sample draws on Philox stream 1; make_golden.py asserted bit-equality of loss and last logits with
+    this oracle function at generation time."""
+    g = load("native_forward.npz")
+    cfg, _, texts, proms, orc = native_setup(dtype)
+    resps = torch.from_numpy(g["resps"].astype(np.int64))
+    seed = int(g["seed"])
+
+    def q_noise(t):
+        return torch.from_numpy(philox.uniform_batch(seed, t, 0, 1, cfg.canvas, stream=philox.STREAM_Q_SAMPLE))[0]
+
+    with torch.no_grad():
+        loss, x = O.training_forward(orc.sd, orc.shape, texts[0], proms[0], resps, q_noise)
+    ref_loss = float(g[f"loss_{tag}"])
+    ref_rows = torch.from_numpy(g[f"last_logits_rows_{tag}"]) if dtype == torch.float32 else f16(g[f"last_logits_rows_{tag}"])
+    if same_platform_as_golden():
+        assert float(loss) == ref_loss and torch.equal(x[g_rows()], ref_rows)
+    else:
+        assert abs(float(loss) - ref_loss) < (1e-4 if dtype == torch.float32 else 5e-3)
+    assert 1.0 < ref_loss < 7.0                      # ~ log(1025) * (1 + masked fraction) / live frames ... order of magnitude
+    assert x.shape == (cfg.canvas, 1025) and bool((x[300:] == 0).all())   # logits of padded frames are zeroed (:683)
+
+
+def g_rows():
+    return load("native_step.npz")["rows"]

@@ -24,6 +24,7 @@ void set_error(const char* fmt, ...) {
 int q_sample_launch(const d3pm_shape*, int, const int32_t*, int32_t*, const uint8_t*, int, const d3pm_schedule*,
                     uint64_t, uint32_t, hipStream_t);
 int uniform_launch(uint64_t, int, uint32_t, int, int, int, float*, hipStream_t);
+int ce_loss_launch(int, const void*, int, const int32_t*, const uint8_t*, int, int, int, float*, hipStream_t);
 void set_gemm_variant(int v);
 void set_gemm_persist_slots(int v);
 void set_attn_qg(int v);
@@ -441,6 +442,14 @@ int d3pm_q_sample(const d3pm_shape* sh, int batch, const int32_t* x0, int32_t* x
   D3PM_REQUIRE(x0 && x_out && frame_mask && sched && sched->dbar && sched->cbar, D3PM_E_ARG, "d3pm_q_sample: null pointer");
   D3PM_REQUIRE(t >= 0 && t < sched->timesteps, D3PM_E_ARG, "t=%d outside the schedule", t);
   return q_sample_launch(sh, batch, x0, x_out, frame_mask, t, sched, seed, utt0, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_ce_loss_rows(const d3pm_shape* sh, int batch, const void* logits, int logits_dtype, const int32_t* targets,
+                      const uint8_t* frame_mask, float* row_loss, void* stream) {
+  D3PM_TRY(check_shape(sh, batch));
+  D3PM_REQUIRE(logits && targets && frame_mask && row_loss, D3PM_E_ARG, "d3pm_ce_loss_rows: null pointer");
+  return ce_loss_launch(logits_dtype, logits, sh->n_classes, targets, frame_mask, sh->canvas, batch * sh->canvas,
+                        sh->n_classes, row_loss, static_cast<hipStream_t>(stream));
 }
 
 int d3pm_uniform(uint64_t seed, int t, uint32_t row0, int rows, int n_classes, int stream_id, float* out, void* stream) {

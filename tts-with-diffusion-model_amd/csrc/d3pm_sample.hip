@@ -202,6 +202,45 @@ int q_sample_launch(const d3pm_shape* sh, int batch, const int32_t* x0, int32_t*
   return D3PM_OK;
 }
 
+// Training-side loss rows (ar_discrete.py:683-690): x = logits * mask (a padded frame becomes an all-zero row, i.e. a
+// uniform prediction), target = x0 * mask, row loss = logsumexp(x) - x[target]; the caller takes the mean over the
+// canvas.  One wave per row, fp32 arithmetic on the logits as stored.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_loss_rows(const T* __restrict__ logits, int ldl, const int32_t* __restrict__ targets,
+                                                    const uint8_t* __restrict__ frame_mask, int canvas, int rows, int K,
+                                                    float* __restrict__ row_loss) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (row >= rows) return;
+  if (!frame_mask[row % canvas]) {
+    if (lane == 0) row_loss[row] = logf(static_cast<float>(K));
+    return;
+  }
+  const T* lr = logits + static_cast<size_t>(row) * ldl;
+  float mx = -INFINITY;
+  for (int j = lane; j < K; j += kWave) mx = fmaxf(mx, static_cast<float>(lr[j]));
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < K; j += kWave) sum += expf(static_cast<float>(lr[j]) - mx);
+  sum = wave_sum(sum);
+  int tg = targets[row];
+  tg = tg < 0 ? 0 : (tg >= K ? K - 1 : tg);
+  if (lane == 0) row_loss[row] = mx + logf(sum) - static_cast<float>(lr[tg]);
+}
+
+int ce_loss_launch(int dtype, const void* logits, int ldl, const int32_t* targets, const uint8_t* frame_mask, int canvas,
+                   int rows, int K, float* row_loss, hipStream_t s) {
+  const dim3 grid((rows + 3) / 4), block(256);
+  switch (dtype) {
+    case D3PM_F32: ce_loss_rows<float><<<grid, block, 0, s>>>(static_cast<const float*>(logits), ldl, targets, frame_mask, canvas, rows, K, row_loss); break;
+    case D3PM_F16: ce_loss_rows<f16><<<grid, block, 0, s>>>(static_cast<const f16*>(logits), ldl, targets, frame_mask, canvas, rows, K, row_loss); break;
+    case D3PM_BF16: ce_loss_rows<bf16><<<grid, block, 0, s>>>(static_cast<const bf16*>(logits), ldl, targets, frame_mask, canvas, rows, K, row_loss); break;
+    default: set_error("unknown logits dtype %d", dtype); return D3PM_E_ARG;
+  }
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
 int uniform_launch(uint64_t seed, int t, uint32_t row0, int rows, int K, int stream_id, float* out, hipStream_t s) {
   size_t n = static_cast<size_t>(rows) * ((K + 3) / 4);
   uniform_rows<<<static_cast<unsigned>((n + 255) / 256), 256, 0, s>>>(seed, t, row0, rows, K, stream_id, out);

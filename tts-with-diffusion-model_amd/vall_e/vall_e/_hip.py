@@ -108,6 +108,8 @@ SIGNATURES = {
                                    C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "d3pm_q_sample": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_void_p]),
+    "d3pm_ce_loss_rows": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "d3pm_uniform": (C.c_int, [C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "d3pm_nar_workspace_bytes": (C.c_size_t, [C.POINTER(NarShape), C.c_int, C.c_int]),
     "d3pm_nar_level": (C.c_int, [C.POINTER(NarShape), C.POINTER(NarWeights), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -335,6 +337,33 @@ class Sampler:
                                      C.byref(self.schedule.c_struct), seed, utt0, flags, _p(ws), ws.numel(), _p(tr),
                                      stream_ptr()), "d3pm_sample_loop")
         return tr
+
+    def ce_loss_rows(self, logits, targets, frame_mask):
+        """fp32 [B, canvas] cross-entropy rows of masked logits against masked targets (d3pm_ce_loss_rows)."""
+        B = logits.shape[0]
+        logits = logits.contiguous()
+        out = torch.empty((B, self.cfg.canvas), dtype=torch.float32, device=self.device)
+        check(lib().d3pm_ce_loss_rows(C.byref(self.shape), B, _p(logits), dtype_code(logits.dtype), _p(targets),
+                                      _p(frame_mask), _p(out), stream_ptr()), "d3pm_ce_loss_rows")
+        return out
+
+    def training_forward(self, x0, frame_mask, kv_t, kv_p, seed, utt0=0, timesteps=None):
+        """The training-side forward of AR.forward (ar_discrete.py:655-693) for utterances that share one frame mask:
+        sum over t = 1 .. timesteps-1 of mean_rows CE(denoiser(q_sample(x0, t)), x0 * mask), divided by mask.sum().
+        Returns (loss fp32 [B], logits of the last step [B, canvas, K] with padded frames zeroed)."""
+        T = self.schedule.timesteps if timesteps is None else int(timesteps)
+        fm = frame_mask.to(torch.uint8)
+        live = fm.bool()
+        targets = (x0 * fm.to(x0.dtype)[None, :]).to(torch.int32).contiguous()
+        total = torch.zeros(x0.shape[0], dtype=torch.float32, device=self.device)
+        logits = None
+        for t in range(1, T):
+            x_t = self.q_sample(x0, fm, t, seed, utt0)
+            logits, _ = self.denoise(x_t, fm, t, kv_t, kv_p)
+            total += self.ce_loss_rows(logits, targets, fm).mean(dim=1)
+        if logits is not None:
+            logits = logits * live[None, :, None].to(logits.dtype)
+        return total / live.sum().to(torch.float32), logits
 
     def sample_loop_graphed(self, x, frame_mask, t_start, t_stop, kv_t, kv_p, seed, utt0=0, flags=0):
         """The same loop replayed from a captured HIP graph: one launch instead of ~50 per iteration, for the

@@ -286,6 +286,30 @@ class AR(nn.Module):
         fm = mask.to(torch.uint8).contiguous()
         return smp.q_sample(x_start.to(torch.int32).contiguous(), fm, int(t.reshape(-1)[0]), seed, utt0).long()
 
-    def forward(self, text_list, proms_list, resps_list=None, spkr_name=None):
-        raise NotImplementedError("training forward (ar_discrete.py:588-694) is outside the sampler's scope; "
-                                  "only generate_audio / p_sample / q_sample are implemented")
+    @torch.no_grad()
+    def forward(self, text_list, proms_list, resps_list=None, spkr_name=None, *, seed: Optional[int] = None):
+        """Training-side forward, evaluation only (forward half; ar_discrete.py:588-694): for every
+        utterance, x_0 = the target codes zero-padded / truncated to the canvas, mask = (x_0 != 0), and
+            loss = sum_{t=1}^{timesteps-1} mean_canvas CE(final(blocks(q_sample(x_0, t))) * mask, x_0 * mask) / mask.sum().
+        Sets `self.loss` (mean over the utterances; upstream indexes `[0]` throughout, so for one utterance this is its
+        value) and returns the masked logits of the last step of the last utterance, `[canvas, n_classes]`, as upstream.
+        q_sample draws Philox stream 1 keyed by `seed` instead of torch.rand.  No autograd graph is built: the backward
+        pass is not part of this build, the loss serves validation / parity."""
+        if resps_list is None or not (len(text_list) == len(proms_list) == len(resps_list)) or len(text_list) == 0:
+            raise ValueError("text_list, proms_list and resps_list must be non-empty and of equal length")
+        smp = self.sampler()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        losses, last = [], None
+        with torch.cuda.device(self.device):
+            for b, (text, prom, resps) in enumerate(zip(text_list, proms_list, resps_list)):
+                r = resps.reshape(-1).to(self.device).long()[: self.cfg.canvas]
+                x0 = F.pad(r, (0, self.cfg.canvas - r.shape[0])).to(torch.int32)[None].contiguous()
+                frame_mask = (x0[0] != 0).to(torch.uint8)
+                cond_text, cond_prompt = self.encode_conditions([text], [prom])
+                kv_t, kv_p = smp.cond_kv(cond_text, cond_prompt)
+                loss, logits = smp.training_forward(x0, frame_mask, kv_t, kv_p, seed, utt0=b, timesteps=self.timesteps)
+                losses.append(loss[0])
+                last = logits[0]
+        self.loss = torch.stack(losses).mean()
+        return last
