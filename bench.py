@@ -234,7 +234,7 @@ def main():
                               "algorithmic_bytes_per_launch": gemm_bytes / max(launches, 1),
                               "algorithmic_flops_per_launch": gemm_flops / max(launches, 1),
                               "launches_timed": launches, "avg_launch_us": gemm_ms * 1e3 / max(launches, 1),
-                              "timing": "HIP event pairs on the launch stream around every GEMM launch of each 8th "
+                              "timing": "HIP event pairs on the launch stream around every GEMM launch of each 16th "
                                         "diffusion iteration of the timed region (all launches cost ~6 % of the step)"}
         whole = algorithmic_flops_per_step(cfg, batch) * iters / (cfg.timesteps - 1) / (ms_per_step * 1e-3) / 1e12
         result["whole_step_tflops"] = whole

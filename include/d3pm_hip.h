@@ -280,7 +280,7 @@ enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GE
 int d3pm_set_tuning(int knob, int value);
 
 /* Timing hooks for bench.py's roofline object: when enabled, every launch of the kernel class
- * `kclass` (D3PM_K_*) inside d3pm_sample_loop is bracketed by a hipEvent pair on `stream` (in every 8th
+ * `kclass` (D3PM_K_*) inside d3pm_sample_loop is bracketed by a hipEvent pair on `stream` (in every 16th
  * diffusion iteration only, so that the event pairs do not perturb the timed region they measure);
  * d3pm_prof_read synchronises those events and returns launch count and total milliseconds. */
 enum { D3PM_K_GEMM = 0, D3PM_K_ATTN = 1, D3PM_K_SAMPLE = 2, D3PM_K_LN = 3, D3PM_K_COUNT = 4 };
