@@ -475,3 +475,19 @@ def test_training_forward_loss_matches_the_reference(tag, n16, n32):
     # two utterances = two independent single-utterance runs, averaged
     two = n.model([n.texts[0], n.texts[1]], [n.proms[0], n.proms[1]], [resps, resps[:200]], seed=seed)
     assert two.shape == last.shape and torch.isfinite(n.model.loss)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_ce_loss_rows_against_torch(n32, dtype):
+    """d3pm_ce_loss_rows = F.cross_entropy(logits * mask, targets * mask, reduction='none') in fp32 (ar_discrete.py:683-690)."""
+    cfg, smp = n32.cfg, n32.smp
+    g = torch.Generator(device="cpu").manual_seed(3)
+    logits = (torch.randn(2, cfg.canvas, cfg.n_classes, generator=g) * 3).to(dtype).to(DEV)
+    x0 = torch.randint(0, cfg.n_classes, (2, cfg.canvas), generator=g).to(torch.int32).to(DEV)
+    mask = (torch.rand(cfg.canvas, generator=g) < 0.7).to(torch.uint8).to(DEV)
+    targets = (x0 * mask[None].to(torch.int32)).contiguous()
+    got = smp.ce_loss_rows(logits, targets, mask)
+    x = logits.float() * mask[None, :, None].float()
+    ref = torch.nn.functional.cross_entropy(x.reshape(-1, cfg.n_classes), targets.reshape(-1).long(), reduction="none").reshape(2, -1)
+    assert (got - ref).abs().max().item() < 2e-5
+    assert torch.allclose(got[:, mask == 0], torch.full_like(got[:, mask == 0], float(np.log(cfg.n_classes))), atol=1e-6)
