@@ -32,6 +32,23 @@ __global__ void embed_rows(const int32_t* __restrict__ tok, const uint8_t* __res
   for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = live ? src[c] : static_cast<T>(0.f);
 }
 
+// the same gather with 16-byte accesses: one wave per row, four rows per workgroup (rows of 16-byte multiples)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_rows_vec(const int32_t* __restrict__ tok, const uint8_t* __restrict__ frame_mask,
+                                                      int canvas, const T* __restrict__ table, T* __restrict__ y, int M,
+                                                      int d, int n_classes) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  int id = tok[row];
+  id = id < 0 ? 0 : (id >= n_classes ? n_classes - 1 : id);
+  const bool live = frame_mask[row % canvas] != 0;
+  const uint4* src = reinterpret_cast<const uint4*>(table + static_cast<size_t>(id) * d);
+  uint4* dst = reinterpret_cast<uint4*>(y + static_cast<size_t>(row) * d);
+  const int n16 = d * static_cast<int>(sizeof(T)) / 16;
+  for (int c = lane; c < n16; c += kWave) dst[c] = live ? src[c] : uint4{0u, 0u, 0u, 0u};
+}
+
 // ------------------------------------------------------------------------------------------
 // one wave per row; two-pass moments in fp32
 template <typename T>
@@ -250,9 +267,16 @@ template <typename F> int dispatch(int dtype, F&& f) {
 int embed_tokens(int dtype, const EmbedArgs& a, hipStream_t s) {
   return dispatch(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    int threads = a.d >= 256 ? 256 : (a.d >= 128 ? 128 : 64);
-    embed_rows<T><<<a.M, threads, 0, s>>>(a.tokens, a.frame_mask, a.canvas, static_cast<const T*>(a.table),
-                                          static_cast<T*>(a.Y), a.M, a.d, a.n_classes);
+    const bool vec = (a.d * sizeof(T)) % 16 == 0 && reinterpret_cast<uintptr_t>(a.table) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(a.Y) % 16 == 0 && a.d * sizeof(T) >= 256;
+    if (vec) {
+      embed_rows_vec<T><<<(a.M + 3) / 4, 256, 0, s>>>(a.tokens, a.frame_mask, a.canvas, static_cast<const T*>(a.table),
+                                                      static_cast<T*>(a.Y), a.M, a.d, a.n_classes);
+    } else {
+      int threads = a.d >= 256 ? 256 : (a.d >= 128 ? 128 : 64);
+      embed_rows<T><<<a.M, threads, 0, s>>>(a.tokens, a.frame_mask, a.canvas, static_cast<const T*>(a.table),
+                                            static_cast<T*>(a.Y), a.M, a.d, a.n_classes);
+    }
     D3PM_LAUNCH_CHECK();
     return D3PM_OK;
   });
