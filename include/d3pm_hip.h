@@ -274,9 +274,12 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *                         Results are bit-identical across schedules.
  * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention: 0 = auto (default: 2 when that still
  *                         gives >= 4 workgroups per CU, else 1), 1 or 2.
+ * D3PM_TUNE_ATTN_PAIR_SEQUENTIAL: 1 (default) = a paired attention launch (text + prompt cross-attention) runs both
+ *                         problems in every workgroup, one after the other; 0 = the second half of the grid takes problem 2.
  * D3PM_TUNE_GEMM_PERSIST_SLOTS: resident workgroups of the persistent throughput schedule, a multiple of 8
  *                         (default 1024 = 4 per CU). */
-enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2 };
+enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2,
+       D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3 };
 int d3pm_set_tuning(int knob, int value);
 
 /* Timing hooks for bench.py's roofline object: when enabled, every launch of the kernel class

@@ -27,6 +27,7 @@ int uniform_launch(uint64_t, int, uint32_t, int, int, int, float*, hipStream_t);
 int ce_loss_launch(int, const void*, int, const int32_t*, const uint8_t*, int, int, int, float*, hipStream_t);
 void set_gemm_variant(int v);
 void set_gemm_persist_slots(int v);
+void set_attn_pair_sequential(int v);
 void set_attn_qg(int v);
 
 // ---- profiling hooks (bench.py roofline object) ----------------------------------------------
@@ -590,6 +591,7 @@ int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const vo
 int d3pm_set_tuning(int knob, int value) {
   if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || value == 2 || value == 3 || value == 5)) { set_gemm_variant(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && value >= 0 && value <= 2) { set_attn_qg(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && (value == 0 || value == 1)) { set_attn_pair_sequential(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_PERSIST_SLOTS && value >= 8 && value <= 4096 && value % 8 == 0) { set_gemm_persist_slots(value); return D3PM_OK; }
   set_error("d3pm_set_tuning: unknown knob %d / value %d", knob, value);
   return D3PM_E_ARG;

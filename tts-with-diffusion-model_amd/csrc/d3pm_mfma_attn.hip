@@ -71,8 +71,8 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2v){a, b}, pair));
 }
 
-template <typename T, int QG>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
-__global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
+template <typename T, int QG, bool PAIR>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
+__global__ __launch_bounds__(256, QG == 1 ? 4 : (PAIR ? 3 : 2)) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
                                                       const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo,
                                                       int Tq, int S, float scale, int H, int n_qblocks,
                                                       const T* __restrict__ Q2, const T* __restrict__ K2,
@@ -88,11 +88,18 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
     const int nblocks = gridDim.x, q = nblocks >> 3, r = nblocks & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  if (bid >= n_first) {   // second problem of a paired launch (block-uniform)
+  // Paired launch (the text and prompt cross-attentions of a block: same queries' rows, different Q / K / V): n_first
+  // < 0 -> every workgroup runs problem 1 and then problem 2 for its query block, sharing its fixed costs (half the
+  // workgroups; the 50-key text problem alone is a single tile per workgroup); n_first >= 0 -> the second half of the
+  // grid takes problem 2.
+  const bool sequential = PAIR && n_first < 0;
+  if (!sequential && bid >= n_first) {   // block-uniform
     bid -= n_first;
     Q = Q2; Kp = K2; Vp = V2; O = O2; S = S2;
   }
   const int qb = bid % n_qblocks, h = (bid / n_qblocks) % H, b = bid / (n_qblocks * H);
+  for (int prob = 0; prob < (PAIR ? 2 : 1); ++prob) {
+  if (prob == 1) { Q = Q2; Kp = K2; Vp = V2; O = O2; S = S2; }
   const int S_pad = S;                                 // row stride of the K/V batches
   if (key_len) S = min(key_len[b], S_pad);             // valid keys of this utterance (>= 1)
   const int q0 = (qb * 4 + wave) * (16 * QG);
@@ -271,6 +278,7 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
       }
     }
   }
+  }   // problems of a sequential pair
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -289,22 +297,31 @@ bool mfma_attention_supported(int dtype, const AttnArgs& a) {
 // 768 x 768 x 256-head self-attention, 27.7 vs 30.1 us on the 225-key prompt attention) once that still leaves >= 4
 // workgroups per CU, one group otherwise (a single utterance is 48 workgroups of two groups: latency regime)
 static int g_attn_qg = 0;
+static bool g_attn_pair_seq = true;
 void set_attn_qg(int v) { g_attn_qg = v; }
+void set_attn_pair_sequential(int v) { g_attn_pair_seq = v != 0; }
 
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
   const long long wgs2 = static_cast<long long>((a.Tq + 127) / 128) * a.H * a.B * (a.Q2 ? 2 : 1);
   const int qg = g_attn_qg == 0 ? (wgs2 >= 4 * 256 ? 2 : 1) : g_attn_qg, per_block = 64 * qg;
   const int n_qblocks = (a.Tq + per_block - 1) / per_block;
-  const int n_first = n_qblocks * a.H * a.B;
-  dim3 grid(static_cast<unsigned>(n_first) * (a.Q2 ? 2 : 1)), block(256);
-#define D3PM_ATTN(T, QG)                                                                                             \
-  attn_mfma_hd64<T, QG><<<grid, block, 0, s>>>(static_cast<const T*>(a.Q), a.ldq, static_cast<const T*>(a.K),        \
-                                               static_cast<const T*>(a.V), a.ldkv, static_cast<T*>(a.O), a.ldo, a.Tq, \
-                                               a.S, a.scale, a.H, n_qblocks, static_cast<const T*>(a.Q2),                 \
-                                               static_cast<const T*>(a.K2), static_cast<const T*>(a.V2),                 \
-                                               static_cast<T*>(a.O2), a.S2, n_first, a.key_len)
-  if (dtype == D3PM_F16) { if (qg == 1) D3PM_ATTN(f16, 1); else D3PM_ATTN(f16, 2); }
-  else { if (qg == 1) D3PM_ATTN(bf16, 1); else D3PM_ATTN(bf16, 2); }
+  const int n_blocks1 = n_qblocks * a.H * a.B;
+  const bool seq = a.Q2 != nullptr && g_attn_pair_seq;
+  const int n_first = seq ? -1 : n_blocks1;
+  dim3 grid(static_cast<unsigned>(n_blocks1) * ((a.Q2 && !seq) ? 2 : 1)), block(256);
+#define D3PM_ATTN(T, QG, PAIR)                                                                                       \
+  attn_mfma_hd64<T, QG, PAIR><<<grid, block, 0, s>>>(static_cast<const T*>(a.Q), a.ldq, static_cast<const T*>(a.K),  \
+                                                     static_cast<const T*>(a.V), a.ldkv, static_cast<T*>(a.O), a.ldo, a.Tq, \
+                                                     a.S, a.scale, a.H, n_qblocks, static_cast<const T*>(a.Q2),           \
+                                                     static_cast<const T*>(a.K2), static_cast<const T*>(a.V2),           \
+                                                     static_cast<T*>(a.O2), a.S2, n_first, a.key_len)
+#define D3PM_ATTN_QG(T)                                                                    \
+  do {                                                                                     \
+    if (seq) { if (qg == 1) D3PM_ATTN(T, 1, true); else D3PM_ATTN(T, 2, true); }           \
+    else { if (qg == 1) D3PM_ATTN(T, 1, false); else D3PM_ATTN(T, 2, false); }             \
+  } while (0)
+  if (dtype == D3PM_F16) D3PM_ATTN_QG(f16); else D3PM_ATTN_QG(bf16);
+#undef D3PM_ATTN_QG
 #undef D3PM_ATTN
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;

@@ -498,6 +498,10 @@ def set_attn_query_groups(v: int):
     check(lib().d3pm_set_tuning(1, v), "d3pm_set_tuning")
 
 
+def set_attn_pair_sequential(v: bool):
+    check(lib().d3pm_set_tuning(3, 1 if v else 0), "d3pm_set_tuning")
+
+
 def set_gemm_persist_slots(v: int):
     check(lib().d3pm_set_tuning(2, v), "d3pm_set_tuning")
 
