@@ -72,7 +72,7 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
 }
 
 template <typename T, int QG, bool PAIR>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
-__global__ __launch_bounds__(256, QG == 1 ? 4 : (PAIR ? 3 : 2)) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
+__global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
                                                       const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo,
                                                       int Tq, int S, float scale, int H, int n_qblocks,
                                                       const T* __restrict__ Q2, const T* __restrict__ K2,
