@@ -94,6 +94,60 @@ __global__ void adaln_rows(const T* __restrict__ x, T* __restrict__ y, const T* 
   }
 }
 
+// the same with 16-byte accesses for d_model a multiple of 512 (16-bit storage): lane l owns elements 8l .. 8l+7 of
+// every 512-element chunk, the row is read once and kept in registers
+template <typename T> struct alignas(16) Row8 { T v[8]; };
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void adaln_rows_vec(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ emb_row,
+                                                      const uint8_t* __restrict__ row_mask, int M, float eps, float k, float cc) {
+  constexpr int d = CH * 512;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  T* yr = y + static_cast<size_t>(row) * d;
+  if (!row_mask[row]) {
+    Row8<T> z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z.v[i] = static_cast<T>(0.f);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) *reinterpret_cast<Row8<T>*>(yr + (c * 64 + lane) * 8) = z;
+    return;
+  }
+  const T* xr = x + static_cast<size_t>(row) * d;
+  float v[CH][8], s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const Row8<T> raw = *reinterpret_cast<const Row8<T>*>(xr + (c * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[c][i] = static_cast<float>(raw.v[i]); s += v[c][i]; }
+  }
+  const float mean = wave_sum(s) / static_cast<float>(d);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float t = v[c][i] - mean; q += t * t; }
+  const float rstd = rsqrtf(wave_sum(q) / static_cast<float>(d) + eps);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    const Row8<T> lg = *reinterpret_cast<const Row8<T>*>(emb_row + col), be = *reinterpret_cast<const Row8<T>*>(emb_row + d + col);
+    Row8<T> o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float h = rn<T>((v[c][i] - mean) * rstd);
+      float a = rn<T>(k * h);
+      a = rn<T>(1.0f - a);
+      a = rn<T>(cc * a);
+      a = rn<T>(a * h);
+      const float g = rn<T>(expf(static_cast<float>(lg.v[i])));
+      o.v[i] = static_cast<T>(rn<T>(g * a) + static_cast<float>(be.v[i]));
+    }
+    *reinterpret_cast<Row8<T>*>(yr + col) = o;
+  }
+}
+
 // one wave per response frame: argmax_j rn(logit_j / T) + gumbel(u_j); writes level `level + 1` of the frame
 template <typename T>
 __global__ void nar_sample_rows(const T* __restrict__ logits, int ldl, const int32_t* __restrict__ lens,
@@ -155,8 +209,17 @@ int nar_embed(int dtype, const NarEmbedArgs& a, hipStream_t s) {
 int adaln(int dtype, const void* x, void* y, const void* emb_row, const uint8_t* row_mask, int M, int d, hipStream_t s) {
   return dispatch(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    adaln_rows<T><<<(M + 3) / 4, 256, 0, s>>>(static_cast<const T*>(x), static_cast<T*>(y), static_cast<const T*>(emb_row),
-                                              row_mask, M, d, 1e-5f, 0.1f, 2.0f);
+    auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    const bool vec = sizeof(T) == 2 && (d == 512 || d == 1024) && al(x) && al(y) && al(emb_row);
+    if (vec && d == 1024)
+      adaln_rows_vec<T, 2><<<(M + 3) / 4, 256, 0, s>>>(static_cast<const T*>(x), static_cast<T*>(y), static_cast<const T*>(emb_row),
+                                                       row_mask, M, 1e-5f, 0.1f, 2.0f);
+    else if (vec)
+      adaln_rows_vec<T, 1><<<(M + 3) / 4, 256, 0, s>>>(static_cast<const T*>(x), static_cast<T*>(y), static_cast<const T*>(emb_row),
+                                                       row_mask, M, 1e-5f, 0.1f, 2.0f);
+    else
+      adaln_rows<T><<<(M + 3) / 4, 256, 0, s>>>(static_cast<const T*>(x), static_cast<T*>(y), static_cast<const T*>(emb_row),
+                                                row_mask, M, d, 1e-5f, 0.1f, 2.0f);
     D3PM_LAUNCH_CHECK();
     return D3PM_OK;
   });
