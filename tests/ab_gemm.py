@@ -1,0 +1,30 @@
+"""Interleaved A/B of GEMM tuning knobs inside one process: medians over alternating repetitions."""
+import math, statistics, sys, torch
+sys.path.insert(0, "tts-with-diffusion-model_amd")
+from vall_e.vall_e import _hip
+DEV, dtype = "cuda", torch.bfloat16
+
+
+def timeit(f, n=10):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+shapes = [("qkv", 24576, 1536, 512, 0, False), ("merged-q", 49152, 512, 512, 0, False), ("proj", 24576, 512, 512, 0, True),
+          ("fc1+gelu", 24576, 2048, 512, 1, False), ("fc2+res", 24576, 512, 2048, 0, True)]
+for name, M, N, K, act, res in shapes:
+    x = torch.randn(M, K, device=DEV).to(dtype); w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, device=DEV).to(dtype); y = torch.empty(M, N, device=DEV, dtype=dtype)
+    r = torch.randn(M, N, device=DEV).to(dtype) if res else None
+    f = lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=N)
+    res_t = {2: [], 5: []}
+    for rep in range(7):
+        for variant in (2, 5):                      # persistent vs one tile per workgroup (swap in the knob under test)
+            _hip.set_gemm_variant(variant)
+            res_t[variant].append(timeit(f))
+    print(f"{name:9s} persistent {statistics.median(res_t[2]):7.1f} us | one tile {statistics.median(res_t[5]):7.1f} us", flush=True)
+_hip.set_gemm_variant(0)
