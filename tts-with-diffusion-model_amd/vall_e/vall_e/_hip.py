@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 F32, F16, BF16 = 0, 1, 2
+ABI_VERSION = 2
 FLAG_GREEDY, FLAG_FORCE_GENERIC, FLAG_SEED_IN_HBM = 1, 2, 4
 K_GEMM, K_ATTN, K_SAMPLE, K_LN = 0, 1, 2, 3
 
@@ -142,7 +143,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.d3pm_abi_version() != 1:
+        if handle.d3pm_abi_version() != ABI_VERSION:
             raise RuntimeError("libd3pm_hip.so ABI version mismatch")
         _lib = handle
     return _lib
