@@ -30,13 +30,37 @@ def _fake_generate(texts, proms, *, seed, utt0):
     return torch.stack(rows) if len(rows) > 1 else rows[0]
 
 
+class _FakeAR:
+    class cfg:
+        canvas, n_frames = 16, 12
+    device = torch.device("cpu")
+
+
+class _FakeNAR:
+    n_resp_levels, n_tokens = 7, 1024
+
+
+def _fake_nar(texts, proms, resps, *, seed, utt0):
+    out = []
+    for b, r in enumerate(resps):
+        g = torch.Generator().manual_seed(seed * 7919 + utt0 + b)
+        rest = torch.randint(0, 1024, (r.shape[0], 7), generator=g)
+        out.append(torch.cat([r.long(), rest], dim=-1))
+    return out
+
+
+def _two_stage(dp, n_utts):
+    texts = [torch.tensor([i]) for i in range(n_utts)]
+    return dp.generate_codes_dp(_FakeAR(), _FakeNAR(), texts, texts, seed=3, ar_fn=_fake_generate, nar_fn=_fake_nar)
+
+
 def _worker(rank, world, port, n_utts, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from vall_e.vall_e import dp
     texts = [torch.tensor([i]) for i in range(n_utts)]
     out = dp.generate_audio_dp(_FakeModel(), texts, texts, seed=3, generate_fn=_fake_generate)
-    q.put((rank, out))
+    q.put((rank, out, _two_stage(dp, n_utts)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,12 +76,17 @@ def test_dp_gather_equals_single_process(world, n_utts):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_utts, q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = dict(q.get(timeout=120) for _ in range(world))
+    got = [q.get(timeout=120) for _ in range(world)]
+    outs = {r: a for r, a, _ in got}
+    codes = {r: c for r, _, c in got}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    single_codes = _two_stage(dp, n_utts)
+    assert single_codes.shape == (n_utts, 12, 8) and single_codes.dtype == torch.int64
     for r in range(world):
         assert torch.equal(outs[r], single), r
+        assert torch.equal(codes[r], single_codes), r       # D3PM stage -> NAR stage -> one gather, any rank count
 
 
 def test_shard_bounds_cover_everything():

@@ -102,3 +102,25 @@ def test_cli_two_stages_write_a_qnt_file(built_lib, tmp_path):
     assert full.shape == (1, 8, 350) and full.dtype == torch.int64
     assert torch.equal(full[:, :1], lvl0)                             # the NAR stage keeps level 0
     assert 0 <= full[:, 1:].min() and full[:, 1:].max() < 1024
+
+
+def test_two_stage_dp_helper_on_one_gpu(built_lib):
+    """dp.generate_codes_dp with the real models (world size 1): equals running the two stages by hand, and sub-batches
+    started at their global utterance index reproduce the rows of the full batch (what the sharding relies on)."""
+    from vall_e.vall_e import AR, NAR, dp, synth
+    cfg = synth.D3PMConfig.native()
+    ar = AR.from_config(cfg)
+    ar.load_state_dict(synth.make_state_dict(cfg, 0))
+    ar = ar.half().to(DEV)
+    ncfg = synth.NARConfig(d_model=256, n_heads=4, n_layers=2)
+    nar = NAR(ncfg.n_tokens, ncfg.d_model, ncfg.n_heads, ncfg.n_layers)
+    nar.load_state_dict(synth.make_nar_state_dict(ncfg, 0))
+    nar = nar.half().to(DEV)
+    texts, proms = synth.make_inputs(cfg, 3, 1)
+    codes = dp.generate_codes_dp(ar, nar, texts, proms, seed=5, steps=8)
+    assert codes.shape == (3, cfg.n_frames, 8) and codes.dtype == torch.int64
+    lvl0 = ar.generate_audio(texts, proms, seed=5, steps=8)[:, : cfg.n_frames]
+    assert torch.equal(codes[..., 0], lvl0.clamp(max=1023))
+    tail = dp.generate_codes_dp(ar, nar, texts[1:], proms[1:], seed=5, steps=8, ar_fn=lambda t, p, **k: ar.generate_audio(t, p, **{**k, "utt0": k["utt0"] + 1}),
+                                nar_fn=lambda t, p, r, **k: nar(t, p, r, **{**k, "utt0": k["utt0"] + 1}))
+    assert (tail == codes[1:]).float().mean().item() > 0.98

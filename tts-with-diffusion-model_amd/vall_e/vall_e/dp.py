@@ -50,3 +50,40 @@ def generate_audio_dp(model, text_list: Sequence[torch.Tensor], proms_list: Sequ
         a, b = shard_bounds(B, world, r)
         parts.append(recv[r * per: r * per + (b - a)])
     return torch.cat(parts).long()
+
+
+def generate_codes_dp(ar, nar, text_list: Sequence[torch.Tensor], proms_list: Sequence[torch.Tensor], *, seed: int,
+                      group=None, ar_fn: Optional[Callable] = None, nar_fn: Optional[Callable] = None,
+                      **kw) -> torch.Tensor:
+    """Both stages of the reference's inference script (/root/reference/vall_e/__main__.py:60-71) sharded the same way:
+    every rank runs the D3PM stage and then the NAR stage (levels 1..7) for its contiguous slice of the utterances --
+    noise keyed by the global utterance index in both -- and ONE all-gather returns the int64 [B, n_frames, 8] codes
+    to every rank.  No collective sits between the stages: a rank's NAR input is its own D3PM output."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    B = len(text_list)
+    lo, hi = shard_bounds(B, world, rank)
+    n_frames, levels = ar.cfg.n_frames, nar.n_resp_levels + 1
+    gen = ar_fn or ar.generate_audio
+    fill = nar_fn or nar
+    local = None
+    if hi > lo:
+        texts, proms = list(text_list[lo:hi]), list(proms_list[lo:hi])
+        lvl0 = gen(texts, proms, seed=seed, utt0=lo, **kw).reshape(hi - lo, -1)[:, :n_frames]
+        resps = [lvl0[b].clamp(max=nar.n_tokens - 1).reshape(-1, 1) for b in range(hi - lo)]
+        full = fill(texts, proms, resps, seed=seed, utt0=lo)
+        local = torch.stack([f.reshape(n_frames, levels) for f in full]).to(torch.int32)
+    if world == 1:
+        return local.long()
+    dev = local.device if local is not None else ar.device
+    per = -(-B // world)
+    send = torch.zeros((per, n_frames, levels), dtype=torch.int32, device=dev)
+    if local is not None:
+        send[: hi - lo] = local
+    recv = torch.empty((world * per, n_frames, levels), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    parts = []
+    for r in range(world):
+        a, b = shard_bounds(B, world, r)
+        parts.append(recv[r * per: r * per + (b - a)])
+    return torch.cat(parts).long()
