@@ -261,6 +261,15 @@ int d3pm_nar_level(const d3pm_nar_shape *shape, const d3pm_nar_weights *w, int b
 int d3pm_op_linear(int dtype, int family, const void *X, int ldx, const void *W, const void *bias, void *Y,
                    int ldy, const void *R1, const void *R2, int ldr, const uint8_t *row_mask,
                    int mask_period, int M, int N, int K, int act, void *stream);
+/* fp8 (OCP e4m3) fast path, BASELINE.json configs[4] (no reference counterpart: the reference is fp16 only):
+ *   layernorm_fp8: Y8[M][512] = e4m3(LN(X)*w + b [FiLM] / sx[m]), sx[m] = absmax of the row / 448 (fp32), the 16-bit
+ *                  LayerNorm result being exactly d3pm_op_layernorm's;
+ *   linear_fp8:    Y[M][N] = epilogue((X8 . W8^T) * sx[m] * sw[n] + bias) in `out_dtype` (f16 / bf16), fp32 accumulate,
+ *                  act 0 none / 1 GELU; M, N, K multiples of 128, X8 / W8 row-major one byte per element. */
+int d3pm_op_linear_fp8(int out_dtype, const void *X8, int ldx, const float *sx, const void *W8, const float *sw,
+                       const void *bias, void *Y, int ldy, int M, int N, int K, int act, void *stream);
+int d3pm_op_layernorm_fp8(int dtype, const void *X, void *Y8, float *sx, const void *w, const void *b,
+                          const void *film, int M, int d, float eps, void *stream);
 int d3pm_op_attention(int dtype, int family, const void *Q, int ldq, const void *K, const void *V, int ldkv,
                       void *O, int ldo, int B, int Tq, int S, int H, int hd, float scale, void *stream);
 int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const void *b, const void *film,

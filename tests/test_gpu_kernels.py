@@ -208,3 +208,46 @@ def test_layernorm_and_film(built_lib, dtype):
         reff = ref.to(dtype).float() * (1 + film[:d].float()).to(dtype).float()
         reff = reff.to(dtype).float() + film[d:].float()
         assert (yf - reff).abs().max().item() < tol * 2 * max(1.0, reff.abs().max().item())
+
+
+# ---- fp8 (OCP e4m3) fast path, BASELINE.json configs[4]: no reference counterpart, pinned to torch on the SAME codes ----
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layernorm_fp8_is_the_layernorm_then_a_row_scale(built_lib, dtype):
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(21)
+    M, d = 1024, 512
+    x = (torch.randn(M, d, generator=g) * 2).to(dtype).to(DEV)
+    x[5] = 0                                                           # a masked frame: LN(0) = bias
+    w = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype).to(DEV)
+    b = (0.1 * torch.randn(d, generator=g)).to(dtype).to(DEV)
+    film = (0.2 * torch.randn(2 * d, generator=g)).to(dtype).to(DEV)
+    for fl in (None, film):
+        y16 = _hip.op_layernorm(x, w, b, film=fl)                      # the 16-bit result the fp8 row is derived from
+        y8, sx = _hip.op_layernorm_fp8(x, w, b, film=fl)
+        amax = y16.float().abs().amax(dim=1)
+        ref_scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+        assert torch.allclose(sx, ref_scale, rtol=1e-6, atol=0)
+        codes = y8.view(torch.float8_e4m3fn).float()
+        ref_codes = (y16.float() / ref_scale[:, None]).to(torch.float8_e4m3fn).float()
+        assert (codes != ref_codes).float().mean().item() < 2e-3        # ties of the 1/scale rounding aside, the same codes
+        deq = codes * sx[:, None]
+        assert ((deq - y16.float()).abs() <= 0.0665 * y16.float().abs() + 2e-3 * amax[:, None]).all()   # e4m3: 3 mantissa bits
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,act", [(1024, 1536, 512, 0), (2048, 2048, 512, 1), (24576, 1536, 512, 0), (1024, 512, 2048, 0)])
+def test_linear_fp8_against_fp32_on_the_same_codes(built_lib, dtype, M, N, K, act):
+    """Products of two e4m3 numbers are exact in fp32, so the kernel must reproduce a torch fp32 evaluation of the
+    de-quantised operands up to summation order and the final 16-bit rounding."""
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(M + N + act)
+    x8, sx = _hip.quantize_rows_e4m3(torch.randn(M, K, generator=g).to(DEV))
+    w8, sw = _hip.quantize_rows_e4m3((torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV))
+    b = (torch.randn(N, generator=g) * 0.1).to(dtype).to(DEV)
+    y = _hip.op_linear_fp8(x8, sx, w8, sw, b, dtype, act=act)
+    xf = x8.view(torch.float8_e4m3fn).float() * sx[:, None]
+    wf = w8.view(torch.float8_e4m3fn).float() * sw[:, None]
+    ref = xf @ wf.T + b.float()
+    if act:
+        ref = torch.nn.functional.gelu(ref.to(dtype).float())
+    assert_close_lp(y, ref, dtype, f"fp8 linear {M}x{N}x{K} act{act}")

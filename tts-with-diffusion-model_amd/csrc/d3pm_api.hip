@@ -565,6 +565,21 @@ int d3pm_op_linear(int dtype, int family, const void* X, int ldx, const void* W,
   return run_linear(dtype, g, 0, s);
 }
 
+int d3pm_op_linear_fp8(int out_dtype, const void* X8, int ldx, const float* sx, const void* W8, const float* sw, const void* bias,
+                       void* Y, int ldy, int M, int N, int K, int act, void* stream) {
+  D3PM_REQUIRE(X8 && sx && W8 && sw && Y && M > 0 && N > 0 && K > 0, D3PM_E_ARG, "d3pm_op_linear_fp8: bad arguments");
+  D3PM_REQUIRE(fp8_linear_supported(out_dtype, M, N, K, ldx, ldy), D3PM_E_SHAPE,
+               "d3pm_op_linear_fp8: needs M, N, K multiples of 128 and a 16-bit output type");
+  return fp8_linear(out_dtype, static_cast<const uint8_t*>(X8), ldx, sx, static_cast<const uint8_t*>(W8), sw, bias, Y, ldy, M, N,
+                    K, act, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_op_layernorm_fp8(int dtype, const void* X, void* Y8, float* sx, const void* w, const void* b, const void* film, int M,
+                          int d, float eps, void* stream) {
+  D3PM_REQUIRE(X && Y8 && sx && w && b && M > 0, D3PM_E_ARG, "d3pm_op_layernorm_fp8: bad arguments");
+  return layernorm_fp8(dtype, X, static_cast<uint8_t*>(Y8), sx, w, b, film, M, d, eps, static_cast<hipStream_t>(stream));
+}
+
 int d3pm_op_attention(int dtype, int family, const void* Q, int ldq, const void* K, const void* V, int ldkv, void* O,
                       int ldo, int B, int Tq, int S, int H, int hd, float scale, void* stream) {
   D3PM_REQUIRE(Q && K && V && O && B > 0 && Tq > 0 && S > 0 && H > 0 && hd > 0, D3PM_E_ARG, "d3pm_op_attention: bad arguments");

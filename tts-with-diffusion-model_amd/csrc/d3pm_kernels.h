@@ -89,6 +89,13 @@ int cond_embed_prompt(int dtype, const int32_t* codes, int n_levels, const void*
                       int rows, int s_prompt, int d, int n_classes, hipStream_t s);
 int posterior_sample(const SampleArgs& a, hipStream_t s);
 
+// fp8 (OCP e4m3) fast path for the LayerNorm-fed K = d_model projections (d3pm_fp8.hip)
+bool fp8_linear_supported(int out_dtype, int M, int N, int K, int ldx, int ldy);
+int fp8_linear(int out_dtype, const uint8_t* X, int ldx, const float* sx, const uint8_t* W, const float* sw, const void* bias,
+               void* Y, int ldy, int M, int N, int K, int act, hipStream_t s);
+int layernorm_fp8(int dtype, const void* x, uint8_t* y8, float* sx, const void* w, const void* b, const void* film, int M, int d,
+                  float eps, hipStream_t s);
+
 // MFMA family: return D3PM_E_SHAPE when the shape does not fit (caller falls back to generic)
 bool mfma_linear_supported(int dtype, const LinearArgs& a);
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s);

@@ -109,6 +109,10 @@ SIGNATURES = {
                                    C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "d3pm_q_sample": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_void_p]),
+    "d3pm_op_linear_fp8": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "d3pm_op_layernorm_fp8": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "d3pm_ce_loss_rows": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "d3pm_uniform": (C.c_int, [C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -421,6 +425,33 @@ def op_linear(x, w, bias=None, *, act=0, r1=None, r2=None, row_mask=None, mask_p
                                _p(r2), 0 if r1 is None else r1.stride(0), _p(row_mask), mask_period, M, N, K, act,
                                stream_ptr()), "d3pm_op_linear")
     return y[:, :N]
+
+
+def quantize_rows_e4m3(w: torch.Tensor):
+    """[N, K] -> (uint8 e4m3 codes [N, K], fp32 scale [N]) with scale = absmax_row / 448 (the weight side of the fp8
+    path: per output channel; torch's float8_e4m3fn is the OCP format gfx950 computes in)."""
+    wf = w.float()
+    scale = wf.abs().amax(dim=1).clamp_min(1e-30) / 448.0
+    codes = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    return codes.view(torch.uint8).contiguous(), scale.contiguous()
+
+
+def op_layernorm_fp8(x, w, b, film=None, eps=1e-6):
+    M, d = x.shape
+    y8 = torch.empty((M, d), dtype=torch.uint8, device=x.device)
+    sx = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib().d3pm_op_layernorm_fp8(dtype_code(x.dtype), _p(x), _p(y8), _p(sx), _p(w), _p(b), _p(film), M, d, eps,
+                                      stream_ptr()), "d3pm_op_layernorm_fp8")
+    return y8, sx
+
+
+def op_linear_fp8(x8, sx, w8, sw, bias, out_dtype, *, act=0):
+    M, K = x8.shape
+    N = w8.shape[0]
+    y = torch.empty((M, N), dtype=out_dtype, device=x8.device)
+    check(lib().d3pm_op_linear_fp8(dtype_code(out_dtype), _p(x8), x8.stride(0), _p(sx), _p(w8), _p(sw), _p(bias), _p(y), N,
+                                   M, N, K, act, stream_ptr()), "d3pm_op_linear_fp8")
+    return y
 
 
 def op_attention(q, k, v, n_heads, scale, *, family=0):
