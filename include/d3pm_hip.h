@@ -88,6 +88,15 @@ typedef struct d3pm_weights {
   const d3pm_block_weights *blocks;       /* HOST array of n_layers entries               */
 } d3pm_weights;
 
+/* e4m3 copies of the three LayerNorm-fed K = d projection weights of one block for the fp8 fast path (BASELINE.json
+ * configs[4]; built by the caller, e.g. _hip.quantize_rows_e4m3): codes [N][d] one byte per element, row-major, and one
+ * fp32 scale per output channel (W[n][k] ~ code[n][k] * scale[n]).  cross_in covers the q rows only ([d][d]). */
+typedef struct d3pm_fp8_block_weights {
+  const void *attn_in_w8;  const float *attn_in_scale;    /* [3d][d], [3d] */
+  const void *cross_in_w8; const float *cross_in_scale;   /* [d][d],  [d]  */
+  const void *fc1_w8;      const float *fc1_scale;        /* [4d][d], [4d] */
+} d3pm_fp8_block_weights;
+
 /* fp16 bit patterns of the absorbing-state schedule, HOST arrays.
  * betas[timesteps+1]; d,c,dbar,cbar[timesteps]:  Q_t = d_t I + c_t 1 e_M^T,  Qbar_t likewise. */
 typedef struct d3pm_schedule {
@@ -190,6 +199,23 @@ int d3pm_sample_loop(const d3pm_shape *shape, const d3pm_weights *w, int batch, 
                      const void *kv_text, const void *kv_prompt, const d3pm_schedule *sched,
                      uint64_t seed, uint32_t utt0, uint32_t flags, void *workspace,
                      size_t workspace_bytes, int32_t *trace, void *stream);
+
+/* The fp8 fast path (BASELINE.json configs[4]): same contracts as d3pm_denoise_step / d3pm_sample_loop, but norm1 ->
+ * QKV, norm2|norm22 -> the merged cross-attention query projection and norm3(+FiLM) -> fc1 run with e4m3 operands
+ * (LayerNorm rows quantised per row on the fly, weights per output channel from `fp8_blocks`, a HOST array of
+ * n_layers entries; fp32 accumulation, 16-bit outputs).  Requires d_model = 512, a 16-bit model dtype and
+ * batch * canvas a multiple of 128; otherwise (and under D3PM_FLAG_FORCE_GENERIC) the 16-bit path runs.  The reference
+ * has no such mode: tests report agreement against the 16-bit path. */
+int d3pm_denoise_step_fp8(const d3pm_shape *shape, const d3pm_weights *weights,
+                          const d3pm_fp8_block_weights *fp8_blocks, int batch, const int32_t *x_t,
+                          const uint8_t *frame_mask, int t, const void *film, const void *kv_text,
+                          const void *kv_prompt, void *workspace, size_t workspace_bytes, void *logits_out,
+                          void *hidden_out, int only_layers, uint32_t flags, void *stream);
+int d3pm_sample_loop_fp8(const d3pm_shape *shape, const d3pm_weights *weights,
+                         const d3pm_fp8_block_weights *fp8_blocks, int batch, int32_t *x,
+                         const uint8_t *frame_mask, int t_start, int t_stop, const void *film, const void *kv_text,
+                         const void *kv_prompt, const d3pm_schedule *sched, uint64_t seed, uint32_t utt0,
+                         uint32_t flags, void *workspace, size_t workspace_bytes, int32_t *trace, void *stream);
 
 /* Replaces AR.q_sample / q_probs (ar_discrete.py:467-502): forward noising of x0 at step t with
  * Philox stream 1.  x0, x_out device int32 [batch][canvas]. */

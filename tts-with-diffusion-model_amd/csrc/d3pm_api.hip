@@ -136,9 +136,16 @@ static char* at(void* p, size_t elems, size_t es) { return static_cast<char*>(p)
 // hidden state after `layers` blocks is left in ws.x
 static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batch, const int32_t* x_t,
                            const uint8_t* frame_mask, int t, const void* film, const void* kv_text,
-                           const void* kv_prompt, const Workspace& ws, int layers, uint32_t flags, hipStream_t s) {
+                           const void* kv_prompt, const Workspace& ws, int layers, uint32_t flags, hipStream_t s,
+                           const d3pm_fp8_block_weights* f8 = nullptr) {
   const int dt = sh.dtype, d = sh.d_model, H = sh.n_heads, hd = d / H, T = sh.canvas;
   const int n = batch * T;
+  // fp8 fast path (BASELINE.json configs[4]): the three LayerNorm-fed K = d projections take e4m3 operands; the e4m3 rows
+  // and their scales live where the 16-bit LayerNorm outputs would (ws.h | ws.h2 are adjacent: 2 n d 2 bytes)
+  const bool use8 = f8 != nullptr && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && fp8_linear_supported(dt, n, 3 * d, d, d, 3 * d) &&
+                    ws.h2 == at(ws.h, static_cast<size_t>(n) * d, dtype_size(dt));
+  uint8_t* x8 = reinterpret_cast<uint8_t*>(ws.h);
+  float* sx8 = reinterpret_cast<float*>(ws.h2);     // 2 n floats at most (n d 2 bytes available)
   const size_t es = dtype_size(dt);
   const float scale = static_cast<float>(std::sqrt(1.0 / static_cast<double>(hd)));
 
@@ -152,11 +159,18 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     // ---- self-attention ----
     LayerNormArgs ln;
     ln.X = ws.x; ln.Y = ws.h; ln.w = b.norm1_w; ln.b = b.norm1_b; ln.M = n; ln.d = d; ln.eps = 1e-6f;
-    D3PM_TRY(run_layernorm(dt, ln, flags, s));
     LinearArgs g;
     g.X = ws.h; g.ldx = d; g.W = b.attn_in_w; g.bias = b.attn_in_b; g.Y = ws.qkv; g.ldy = 3 * d;
     g.M = n; g.N = 3 * d; g.K = d;
-    D3PM_TRY(run_linear(dt, g, flags, s));
+    if (use8) {
+      D3PM_TRY(layernorm_fp8(dt, ws.x, x8, sx8, b.norm1_w, b.norm1_b, nullptr, nullptr, nullptr, nullptr, nullptr, n, d, 1e-6f, s));
+      ProfScope p(D3PM_K_GEMM, s, 2.0 * g.M * g.N * g.K, 1.0 * g.M * g.K + 1.0 * g.N * g.K + es * g.M * g.N);
+      D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].attn_in_w8), f8[l].attn_in_scale, b.attn_in_b, ws.qkv,
+                          3 * d, n, 3 * d, d, ACT_NONE, s));
+    } else {
+      D3PM_TRY(run_layernorm(dt, ln, flags, s));
+      D3PM_TRY(run_linear(dt, g, flags, s));
+    }
     AttnArgs a;
     a.Q = ws.qkv; a.ldq = 3 * d; a.K = at(ws.qkv, d, es); a.V = at(ws.qkv, 2 * d, es); a.ldkv = 3 * d;
     a.O = ws.att; a.ldo = d; a.B = batch; a.Tq = T; a.S = T; a.H = H; a.hd = hd; a.scale = scale;
@@ -169,16 +183,24 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     ln = LayerNormArgs();
     ln.X = ws.x; ln.Y = ws.h; ln.w = b.norm2_w; ln.b = b.norm2_b; ln.Y2 = ws.h2; ln.w2 = b.norm22_w; ln.b2 = b.norm22_b;
     ln.M = n; ln.d = d; ln.eps = 1e-6f;
-    D3PM_TRY(run_layernorm(dt, ln, flags, s));
     char* q_text = ws.qkv;
     char* q_prom = at(ws.qkv, static_cast<size_t>(n) * d, es);
-    if (ws.h2 == at(ws.h, static_cast<size_t>(n) * d, es)) {
+    if (use8) {
+      // e4m3 rows of norm2(x) | norm22(x) stacked [2n][d] (fills ws.h), scales [2n] at ws.h2: ONE fp8 GEMM for both queries
+      D3PM_TRY(layernorm_fp8(dt, ws.x, x8, sx8, b.norm2_w, b.norm2_b, nullptr, b.norm22_w, b.norm22_b,
+                             x8 + static_cast<size_t>(n) * d, sx8 + n, n, d, 1e-6f, s));
+      ProfScope p(D3PM_K_GEMM, s, 2.0 * 2 * n * d * d, 2.0 * n * d + 1.0 * d * d + es * 2.0 * n * d);
+      D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].cross_in_w8), f8[l].cross_in_scale, b.cross_in_b,
+                          q_text, d, 2 * n, d, d, ACT_NONE, s));
+    } else if (ws.h2 == at(ws.h, static_cast<size_t>(n) * d, es)) {
+      D3PM_TRY(run_layernorm(dt, ln, flags, s));
       // both query projections share cross_attn's q rows: LN2|LN22 outputs and q_text|q_prompt are adjacent in
       // the workspace, so the pair is ONE [2n, d] x [d, d] GEMM (twice the workgroups of either alone)
       g = LinearArgs();
       g.X = ws.h; g.ldx = d; g.W = b.cross_in_w; g.bias = b.cross_in_b; g.Y = q_text; g.ldy = d; g.M = 2 * n; g.N = d; g.K = d;
       D3PM_TRY(run_linear(dt, g, flags, s));
     } else {
+      D3PM_TRY(run_layernorm(dt, ln, flags, s));
       for (int which = 0; which < 2; ++which) {
         g = LinearArgs();
         g.X = which ? ws.h2 : ws.h; g.ldx = d; g.W = b.cross_in_w; g.bias = b.cross_in_b;
@@ -207,11 +229,18 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     ln = LayerNormArgs();
     ln.X = ws.x; ln.Y = ws.h; ln.w = b.norm3_w; ln.b = b.norm3_b; ln.M = n; ln.d = d; ln.eps = 1e-6f;
     ln.film = at(film, (static_cast<size_t>(t) * sh.n_layers + l) * 2 * d, es);
-    D3PM_TRY(run_layernorm(dt, ln, flags, s));
     g = LinearArgs();
     g.X = ws.h; g.ldx = d; g.W = b.fc1_w; g.bias = b.fc1_b; g.Y = ws.mlp; g.ldy = 4 * d; g.M = n; g.N = 4 * d; g.K = d;
     g.act = ACT_GELU;
-    D3PM_TRY(run_linear(dt, g, flags, s));
+    if (use8) {
+      D3PM_TRY(layernorm_fp8(dt, ws.x, x8, sx8, b.norm3_w, b.norm3_b, ln.film, nullptr, nullptr, nullptr, nullptr, n, d, 1e-6f, s));
+      ProfScope p(D3PM_K_GEMM, s, 2.0 * g.M * g.N * g.K, 1.0 * g.M * g.K + 1.0 * g.N * g.K + es * g.M * g.N);
+      D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].fc1_w8), f8[l].fc1_scale, b.fc1_b, ws.mlp, 4 * d, n,
+                          4 * d, d, ACT_GELU, s));
+    } else {
+      D3PM_TRY(run_layernorm(dt, ln, flags, s));
+      D3PM_TRY(run_linear(dt, g, flags, s));
+    }
     g = LinearArgs();
     g.X = ws.mlp; g.ldx = 4 * d; g.W = b.fc2_w; g.bias = b.fc2_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
     g.row_mask = frame_mask; g.mask_period = T; g.M = n; g.N = d; g.K = 4 * d;
@@ -363,10 +392,10 @@ int d3pm_encode_conditions(const d3pm_shape* sh, const d3pm_cond_weights* cw, in
   return run_encoder(*sh, cw->prompt_encoder, batch, sh->s_prompt, ws, cond_prompt, s);
 }
 
-int d3pm_denoise_step(const d3pm_shape* sh, const d3pm_weights* w, int batch, const int32_t* x_t,
-                      const uint8_t* frame_mask, int t, const void* film, const void* kv_text, const void* kv_prompt,
-                      void* workspace, size_t workspace_bytes, void* logits_out, void* hidden_out, int only_layers,
-                      uint32_t flags, void* stream) {
+static int denoise_step_impl(const d3pm_shape* sh, const d3pm_weights* w, int batch, const int32_t* x_t,
+                             const uint8_t* frame_mask, int t, const void* film, const void* kv_text, const void* kv_prompt,
+                             void* workspace, size_t workspace_bytes, void* logits_out, void* hidden_out, int only_layers,
+                             uint32_t flags, void* stream, const d3pm_fp8_block_weights* f8) {
   D3PM_TRY(check_shape(sh, batch));
   D3PM_REQUIRE(w && w->blocks && x_t && frame_mask && film && kv_text && kv_prompt && workspace, D3PM_E_ARG,
                "d3pm_denoise_step: null pointer");
@@ -375,7 +404,7 @@ int d3pm_denoise_step(const d3pm_shape* sh, const d3pm_weights* w, int batch, co
   D3PM_REQUIRE(workspace_bytes >= ws.total, D3PM_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int layers = (only_layers >= 0 && only_layers < sh->n_layers) ? only_layers : sh->n_layers;
-  D3PM_TRY(denoiser_blocks(*sh, *w, batch, x_t, frame_mask, t, film, kv_text, kv_prompt, ws, layers, flags, s));
+  D3PM_TRY(denoiser_blocks(*sh, *w, batch, x_t, frame_mask, t, film, kv_text, kv_prompt, ws, layers, flags, s, f8));
   if (hidden_out)
     D3PM_CHECK_HIP(hipMemcpyAsync(hidden_out, ws.x, static_cast<size_t>(batch) * sh->canvas * sh->d_model * dtype_size(sh->dtype),
                                   hipMemcpyDeviceToDevice, s));
@@ -386,6 +415,23 @@ int d3pm_denoise_step(const d3pm_shape* sh, const d3pm_weights* w, int batch, co
                                     static_cast<size_t>(batch) * sh->canvas, hipMemcpyDeviceToDevice, s));
   }
   return D3PM_OK;
+}
+
+int d3pm_denoise_step(const d3pm_shape* sh, const d3pm_weights* w, int batch, const int32_t* x_t,
+                      const uint8_t* frame_mask, int t, const void* film, const void* kv_text, const void* kv_prompt,
+                      void* workspace, size_t workspace_bytes, void* logits_out, void* hidden_out, int only_layers,
+                      uint32_t flags, void* stream) {
+  return denoise_step_impl(sh, w, batch, x_t, frame_mask, t, film, kv_text, kv_prompt, workspace, workspace_bytes, logits_out,
+                           hidden_out, only_layers, flags, stream, nullptr);
+}
+
+int d3pm_denoise_step_fp8(const d3pm_shape* sh, const d3pm_weights* w, const d3pm_fp8_block_weights* fp8_blocks, int batch,
+                          const int32_t* x_t, const uint8_t* frame_mask, int t, const void* film, const void* kv_text,
+                          const void* kv_prompt, void* workspace, size_t workspace_bytes, void* logits_out, void* hidden_out,
+                          int only_layers, uint32_t flags, void* stream) {
+  D3PM_REQUIRE(fp8_blocks, D3PM_E_ARG, "d3pm_denoise_step_fp8: null fp8 weights");
+  return denoise_step_impl(sh, w, batch, x_t, frame_mask, t, film, kv_text, kv_prompt, workspace, workspace_bytes, logits_out,
+                           hidden_out, only_layers, flags, stream, fp8_blocks);
 }
 
 int d3pm_posterior_sample(const d3pm_shape* sh, int batch, const void* logits, int logits_dtype, const int32_t* x_t,
@@ -403,10 +449,10 @@ int d3pm_posterior_sample(const d3pm_shape* sh, int batch, const void* logits, i
   return posterior_sample(a, static_cast<hipStream_t>(stream));
 }
 
-int d3pm_sample_loop(const d3pm_shape* sh, const d3pm_weights* w, int batch, int32_t* x, const uint8_t* frame_mask,
-                     int t_start, int t_stop, const void* film, const void* kv_text, const void* kv_prompt,
-                     const d3pm_schedule* sched, uint64_t seed, uint32_t utt0, uint32_t flags, void* workspace,
-                     size_t workspace_bytes, int32_t* trace, void* stream) {
+static int sample_loop_impl(const d3pm_shape* sh, const d3pm_weights* w, int batch, int32_t* x, const uint8_t* frame_mask,
+                            int t_start, int t_stop, const void* film, const void* kv_text, const void* kv_prompt,
+                            const d3pm_schedule* sched, uint64_t seed, uint32_t utt0, uint32_t flags, void* workspace,
+                            size_t workspace_bytes, int32_t* trace, void* stream, const d3pm_fp8_block_weights* f8) {
   D3PM_TRY(check_shape(sh, batch));
   D3PM_REQUIRE(w && w->blocks && x && frame_mask && film && kv_text && kv_prompt && sched && workspace, D3PM_E_ARG,
                "d3pm_sample_loop: null pointer");
@@ -418,7 +464,7 @@ int d3pm_sample_loop(const d3pm_shape* sh, const d3pm_weights* w, int batch, int
   const int rows = batch * sh->canvas;
   for (int t = t_start; t > t_stop; --t) {
     g_prof.sample_now = (t % g_prof.stride) == 0;
-    D3PM_TRY(denoiser_blocks(*sh, *w, batch, x, frame_mask, t, film, kv_text, kv_prompt, ws, sh->n_layers, flags, s));
+    D3PM_TRY(denoiser_blocks(*sh, *w, batch, x, frame_mask, t, film, kv_text, kv_prompt, ws, sh->n_layers, flags, s, f8));
     D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, logits_ld(*sh), flags, s));
     SampleArgs a;
     a.logits = ws.logits; a.logits_dtype = sh->dtype; a.ldl = logits_ld(*sh); a.x_t = x; a.x_next = x;
@@ -435,6 +481,23 @@ int d3pm_sample_loop(const d3pm_shape* sh, const d3pm_weights* w, int batch, int
   }
   g_prof.sample_now = true;
   return D3PM_OK;
+}
+
+int d3pm_sample_loop(const d3pm_shape* sh, const d3pm_weights* w, int batch, int32_t* x, const uint8_t* frame_mask,
+                     int t_start, int t_stop, const void* film, const void* kv_text, const void* kv_prompt,
+                     const d3pm_schedule* sched, uint64_t seed, uint32_t utt0, uint32_t flags, void* workspace,
+                     size_t workspace_bytes, int32_t* trace, void* stream) {
+  return sample_loop_impl(sh, w, batch, x, frame_mask, t_start, t_stop, film, kv_text, kv_prompt, sched, seed, utt0, flags,
+                          workspace, workspace_bytes, trace, stream, nullptr);
+}
+
+int d3pm_sample_loop_fp8(const d3pm_shape* sh, const d3pm_weights* w, const d3pm_fp8_block_weights* fp8_blocks, int batch,
+                         int32_t* x, const uint8_t* frame_mask, int t_start, int t_stop, const void* film,
+                         const void* kv_text, const void* kv_prompt, const d3pm_schedule* sched, uint64_t seed, uint32_t utt0,
+                         uint32_t flags, void* workspace, size_t workspace_bytes, int32_t* trace, void* stream) {
+  D3PM_REQUIRE(fp8_blocks, D3PM_E_ARG, "d3pm_sample_loop_fp8: null fp8 weights");
+  return sample_loop_impl(sh, w, batch, x, frame_mask, t_start, t_stop, film, kv_text, kv_prompt, sched, seed, utt0, flags,
+                          workspace, workspace_bytes, trace, stream, fp8_blocks);
 }
 
 int d3pm_q_sample(const d3pm_shape* sh, int batch, const int32_t* x0, int32_t* x_out, const uint8_t* frame_mask, int t,
@@ -577,7 +640,8 @@ int d3pm_op_linear_fp8(int out_dtype, const void* X8, int ldx, const float* sx, 
 int d3pm_op_layernorm_fp8(int dtype, const void* X, void* Y8, float* sx, const void* w, const void* b, const void* film, int M,
                           int d, float eps, void* stream) {
   D3PM_REQUIRE(X && Y8 && sx && w && b && M > 0, D3PM_E_ARG, "d3pm_op_layernorm_fp8: bad arguments");
-  return layernorm_fp8(dtype, X, static_cast<uint8_t*>(Y8), sx, w, b, film, M, d, eps, static_cast<hipStream_t>(stream));
+  return layernorm_fp8(dtype, X, static_cast<uint8_t*>(Y8), sx, w, b, film, nullptr, nullptr, nullptr, nullptr, M, d, eps,
+                       static_cast<hipStream_t>(stream));
 }
 
 int d3pm_op_attention(int dtype, int family, const void* Q, int ldq, const void* K, const void* V, int ldkv, void* O,

@@ -58,10 +58,28 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 // ---- LayerNorm -> e4m3 row -------------------------------------------------------------------------------------
 template <typename T> struct alignas(16) Vec8 { T v[8]; };
 
+__device__ __forceinline__ void store_fp8_row(const float (&o)[8], uint8_t* dst, float* scale_out, int lane) {
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(o[i]));
+  amax = wave_max(amax);
+  const float scale = amax > 0.f ? amax / kFp8Max : 1.0f, inv = 1.0f / scale;
+  uint32_t lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0] * inv, o[1] * inv, lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2] * inv, o[3] * inv, lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4] * inv, o[5] * inv, hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6] * inv, o[7] * inv, hi, true);
+  *reinterpret_cast<uint2*>(dst) = uint2{lo, hi};
+  if (lane == 0) *scale_out = scale;
+}
+
+// optional second LayerNorm of the same rows (w2, b2 -> y8_2, sx_2), as layernorm_vec's dual output (norm2 | norm22)
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fp8_rows(const T* __restrict__ x, uint8_t* __restrict__ y8, float* __restrict__ sx,
                                                           const T* __restrict__ w, const T* __restrict__ b,
-                                                          const T* __restrict__ film, int M, float eps) {
+                                                          const T* __restrict__ film, const T* __restrict__ w2,
+                                                          const T* __restrict__ b2, uint8_t* __restrict__ y8_2,
+                                                          float* __restrict__ sx_2, int M, float eps) {
   constexpr int d = 512;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
@@ -77,7 +95,7 @@ __global__ __launch_bounds__(256) void layernorm_fp8_rows(const T* __restrict__ 
   const float rstd = rsqrtf(wave_sum(q) / static_cast<float>(d) + eps);
   const int col = lane * 8;
   const Vec8<T> wv = *reinterpret_cast<const Vec8<T>*>(w + col), bv = *reinterpret_cast<const Vec8<T>*>(b + col);
-  float o[8], amax = 0.f;
+  float o[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = rn<T>((v[i] - mean) * rstd * static_cast<float>(wv.v[i]) + static_cast<float>(bv.v[i]));
   if (film) {
@@ -88,17 +106,13 @@ __global__ __launch_bounds__(256) void layernorm_fp8_rows(const T* __restrict__ 
       o[i] = rn<T>(rn<T>(o[i] * g) + static_cast<float>(sh.v[i]));
     }
   }
+  store_fp8_row(o, y8 + static_cast<size_t>(row) * d + col, sx + row, lane);
+  if (y8_2) {
+    const Vec8<T> w2v = *reinterpret_cast<const Vec8<T>*>(w2 + col), b2v = *reinterpret_cast<const Vec8<T>*>(b2 + col);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(o[i]));
-  amax = wave_max(amax);
-  const float scale = amax > 0.f ? amax / kFp8Max : 1.0f, inv = 1.0f / scale;
-  uint32_t lo = 0, hi = 0;
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0] * inv, o[1] * inv, lo, false);
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2] * inv, o[3] * inv, lo, true);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4] * inv, o[5] * inv, hi, false);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6] * inv, o[7] * inv, hi, true);
-  *reinterpret_cast<uint2*>(y8 + static_cast<size_t>(row) * d + col) = uint2{lo, hi};
-  if (lane == 0) sx[row] = scale;
+    for (int i = 0; i < 8; ++i) o[i] = rn<T>((v[i] - mean) * rstd * static_cast<float>(w2v.v[i]) + static_cast<float>(b2v.v[i]));
+    store_fp8_row(o, y8_2 + static_cast<size_t>(row) * d + col, sx_2 + row, lane);
+  }
 }
 
 // ---- persistent fp8 GEMM ------------------------------------------------------------------------------------------
@@ -250,16 +264,18 @@ int fp8_linear(int out_dtype, const uint8_t* X, int ldx, const float* sx, const 
   return D3PM_OK;
 }
 
-int layernorm_fp8(int dtype, const void* x, uint8_t* y8, float* sx, const void* w, const void* b, const void* film, int M, int d,
-                  float eps, hipStream_t s) {
+int layernorm_fp8(int dtype, const void* x, uint8_t* y8, float* sx, const void* w, const void* b, const void* film,
+                  const void* w2, const void* b2, uint8_t* y8_2, float* sx_2, int M, int d, float eps, hipStream_t s) {
   D3PM_REQUIRE(d == 512 && (dtype == D3PM_F16 || dtype == D3PM_BF16), D3PM_E_SHAPE, "layernorm_fp8: d = 512, 16-bit input only");
   const dim3 grid((M + 3) / 4), block(256);
   if (dtype == D3PM_F16)
     layernorm_fp8_rows<f16><<<grid, block, 0, s>>>(static_cast<const f16*>(x), y8, sx, static_cast<const f16*>(w),
-                                                   static_cast<const f16*>(b), static_cast<const f16*>(film), M, eps);
+                                                   static_cast<const f16*>(b), static_cast<const f16*>(film),
+                                                   static_cast<const f16*>(w2), static_cast<const f16*>(b2), y8_2, sx_2, M, eps);
   else
     layernorm_fp8_rows<bf16><<<grid, block, 0, s>>>(static_cast<const bf16*>(x), y8, sx, static_cast<const bf16*>(w),
-                                                    static_cast<const bf16*>(b), static_cast<const bf16*>(film), M, eps);
+                                                    static_cast<const bf16*>(b), static_cast<const bf16*>(film),
+                                                    static_cast<const bf16*>(w2), static_cast<const bf16*>(b2), y8_2, sx_2, M, eps);
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;
 }

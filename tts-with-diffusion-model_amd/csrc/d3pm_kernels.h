@@ -93,8 +93,8 @@ int posterior_sample(const SampleArgs& a, hipStream_t s);
 bool fp8_linear_supported(int out_dtype, int M, int N, int K, int ldx, int ldy);
 int fp8_linear(int out_dtype, const uint8_t* X, int ldx, const float* sx, const uint8_t* W, const float* sw, const void* bias,
                void* Y, int ldy, int M, int N, int K, int act, hipStream_t s);
-int layernorm_fp8(int dtype, const void* x, uint8_t* y8, float* sx, const void* w, const void* b, const void* film, int M, int d,
-                  float eps, hipStream_t s);
+int layernorm_fp8(int dtype, const void* x, uint8_t* y8, float* sx, const void* w, const void* b, const void* film,
+                  const void* w2, const void* b2, uint8_t* y8_2, float* sx_2, int M, int d, float eps, hipStream_t s);
 
 // MFMA family: return D3PM_E_SHAPE when the shape does not fit (caller falls back to generic)
 bool mfma_linear_supported(int dtype, const LinearArgs& a);

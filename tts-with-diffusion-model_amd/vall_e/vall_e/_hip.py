@@ -109,6 +109,12 @@ SIGNATURES = {
                                    C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "d3pm_q_sample": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_void_p]),
+    "d3pm_denoise_step_fp8": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]),
+    "d3pm_sample_loop_fp8": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ScheduleC),
+                                       C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "d3pm_op_linear_fp8": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "d3pm_op_layernorm_fp8": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -220,6 +226,27 @@ class DeviceWeights:
                                 ptr("final.bias"), self.blocks)
 
 
+class Fp8BlockWeights(C.Structure):
+    _fields_ = [("attn_in_w8", C.c_void_p), ("attn_in_scale", C.c_void_p), ("cross_in_w8", C.c_void_p),
+                ("cross_in_scale", C.c_void_p), ("fc1_w8", C.c_void_p), ("fc1_scale", C.c_void_p)]
+
+
+class DeviceFp8Weights:
+    """e4m3 copies (per output channel scales) of the LayerNorm-fed projections of every block for the fp8 fast path."""
+
+    def __init__(self, tensors: dict, n_layers: int, d_model: int):
+        self._keep = []
+        self.blocks = (Fp8BlockWeights * n_layers)()
+        for i in range(n_layers):
+            for field, key, rows in (("attn_in", "attn.in_proj_weight", None), ("cross_in", "cross_attn.in_proj_weight", d_model),
+                                     ("fc1", "mlp.fc1.weight", None)):
+                w = tensors[f"blocks.{i}.{key}"]
+                codes, scale = quantize_rows_e4m3(w[:rows] if rows else w)
+                self._keep += [codes, scale]
+                setattr(self.blocks[i], field + "_w8", codes.data_ptr())
+                setattr(self.blocks[i], field + "_scale", scale.data_ptr())
+
+
 class DeviceCondWeights:
     """Pointer tables of the two condition encoders (+ embeddings and position tables)."""
 
@@ -263,6 +290,7 @@ class Sampler:
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.shape = make_shape(cfg, dtype)
         self.weights = DeviceWeights(tensors, cfg.n_layers)
+        self._tensors, self._fp8 = tensors, None
         self.cond_weights = (DeviceCondWeights(tensors, cfg, pe_text0, pe_prompt)
                              if pe_text0 is not None and "encodertext.1.fc1.weight" in tensors else None)
         self._cond_ws = None
@@ -272,6 +300,14 @@ class Sampler:
         self.film = torch.empty((cfg.timesteps + 1, cfg.n_layers, 2 * cfg.d_model), dtype=dtype, device=self.device)
         check(lib().d3pm_film_table(C.byref(self.shape), C.byref(self.weights.c_struct), _p(self.film), stream_ptr()),
               "d3pm_film_table")
+
+    def fp8_weights(self) -> DeviceFp8Weights:
+        """e4m3 weight copies for the fp8 fast path, quantised on first use."""
+        if self._fp8 is None:
+            if self.cfg.d_model != 512 or self.dtype == torch.float32:
+                raise D3PMError("the fp8 fast path needs d_model = 512 and a 16-bit model dtype")
+            self._fp8 = DeviceFp8Weights(self._tensors, self.cfg.n_layers, self.cfg.d_model)
+        return self._fp8
 
     def workspace(self, batch: int, slot: int = 0) -> torch.Tensor:
         """Scratch for one in-flight call; `slot` separates calls that run concurrently on different streams."""
@@ -313,11 +349,17 @@ class Sampler:
         return kv_t, kv_p
 
     def denoise(self, x_t, frame_mask, t, kv_t, kv_p, *, want_logits=True, want_hidden=False, only_layers=-1,
-                flags=0):
+                flags=0, fp8=False):
         cfg, B = self.cfg, x_t.shape[0]
         ws = self.workspace(B)
         logits = torch.empty((B, cfg.canvas, cfg.n_classes), dtype=self.dtype, device=self.device) if want_logits else None
         hidden = torch.empty((B, cfg.canvas, cfg.d_model), dtype=self.dtype, device=self.device) if want_hidden else None
+        if fp8:
+            check(lib().d3pm_denoise_step_fp8(C.byref(self.shape), C.byref(self.weights.c_struct),
+                                              C.cast(self.fp8_weights().blocks, C.c_void_p), B, _p(x_t), _p(frame_mask), int(t),
+                                              _p(self.film), _p(kv_t), _p(kv_p), _p(ws), ws.numel(), _p(logits), _p(hidden),
+                                              only_layers, flags, stream_ptr()), "d3pm_denoise_step_fp8")
+            return logits, hidden
         check(lib().d3pm_denoise_step(C.byref(self.shape), C.byref(self.weights.c_struct), B, _p(x_t), _p(frame_mask),
                                       int(t), _p(self.film), _p(kv_t), _p(kv_p), _p(ws), ws.numel(), _p(logits),
                                       _p(hidden), only_layers, flags, stream_ptr()), "d3pm_denoise_step")
@@ -333,10 +375,18 @@ class Sampler:
                                           _p(post), stream_ptr()), "d3pm_posterior_sample")
         return x_next, post
 
-    def sample_loop(self, x, frame_mask, t_start, t_stop, kv_t, kv_p, seed, utt0=0, flags=0, trace=False, slot=0):
+    def sample_loop(self, x, frame_mask, t_start, t_stop, kv_t, kv_p, seed, utt0=0, flags=0, trace=False, slot=0,
+                    fp8=False):
         cfg, B = self.cfg, x.shape[0]
         ws = self.workspace(B, slot)
         tr = torch.empty((t_start - t_stop, B, cfg.canvas), dtype=torch.int32, device=self.device) if trace else None
+        if fp8:
+            check(lib().d3pm_sample_loop_fp8(C.byref(self.shape), C.byref(self.weights.c_struct),
+                                             C.cast(self.fp8_weights().blocks, C.c_void_p), B, _p(x), _p(frame_mask),
+                                             int(t_start), int(t_stop), _p(self.film), _p(kv_t), _p(kv_p),
+                                             C.byref(self.schedule.c_struct), seed, utt0, flags, _p(ws), ws.numel(), _p(tr),
+                                             stream_ptr()), "d3pm_sample_loop_fp8")
+            return tr
         check(lib().d3pm_sample_loop(C.byref(self.shape), C.byref(self.weights.c_struct), B, _p(x), _p(frame_mask),
                                      int(t_start), int(t_stop), _p(self.film), _p(kv_t), _p(kv_p),
                                      C.byref(self.schedule.c_struct), seed, utt0, flags, _p(ws), ws.numel(), _p(tr),

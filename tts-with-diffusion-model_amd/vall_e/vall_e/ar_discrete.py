@@ -217,10 +217,13 @@ class AR(nn.Module):
     def generate_audio(self, text_list, proms_list, resps_list=None, *, steps: Optional[int] = None,
                        n_frames: Optional[int] = None, seed: Optional[int] = None, greedy: bool = False,
                        utt0: int = 0, return_trace: bool = False, flags: int = 0, streams: Optional[int] = None,
-                       graph: Optional[bool] = None):
+                       graph: Optional[bool] = None, fp8: bool = False):
         """Reverse diffusion for len(text_list) utterances.  Positional behaviour as upstream:
         one utterance -> int64 [canvas] (squeezed, untrimmed; rows >= n_frames are sampled from
         final.bias and meaningless).  `resps_list` is ignored, as upstream ignores it (:699).
+        `fp8=True` is the fast configuration of BASELINE.json configs[4]: the QKV, cross-attention query and fc1
+        projections take e4m3 operands (d_model = 512, 16-bit model, batch * canvas a multiple of 128); the reference
+        has no such mode.
         `graph=True` replays the loop from a captured HIP graph (seed read from HBM, identical results).  Off by
         default: measured on MI355X one utterance takes 66.6 ms replayed and 66.3 ms launched eagerly -- the ~5000
         kernels of a reverse process are bound by their own ~10 us latency at M = 768 rows, not by launch overhead."""
@@ -246,7 +249,7 @@ class AR(nn.Module):
                 smp.sample_loop_graphed(x, frame_mask, t_start, 0, kv_t, kv_p, seed, utt0, fl)
             elif n_streams == 1 or return_trace:
                 kv_t, kv_p = smp.cond_kv(cond_text, cond_prompt)
-                trace = smp.sample_loop(x, frame_mask, t_start, 0, kv_t, kv_p, seed, utt0, fl, trace=return_trace)
+                trace = smp.sample_loop(x, frame_mask, t_start, 0, kv_t, kv_p, seed, utt0, fl, trace=return_trace, fp8=fp8)
             else:
                 # utterances are independent: chunks of the batch run the whole loop on their own stream so that
                 # the short kernels of one chunk fill the ramp-up / epilogue bubbles of the others
