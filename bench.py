@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path with several ranks sharing one GPU (NCCL refuses that)")
     ap.add_argument("--no-nar", action="store_true", help="skip the extra NAR (levels 1..7) measurement")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8 fast-path measurement (BASELINE.json configs[4])")
     ap.add_argument("--streams", type=int, default=1, help="independent batch chunks on separate HIP streams")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket GEMM launches with HIP events (roofline.achieved is then 0): measures what the "
@@ -114,6 +115,34 @@ def nar_stage(dev, dtype, batch, cfg, level0):
     flops = 7.0 * rows * ncfg.n_layers * 24 * ncfg.d_model ** 2       # GEMM flops only (QKV, out, FFN), 7 levels
     return {"model": f"NAR d={ncfg.d_model} H={ncfg.n_heads} L={ncfg.n_layers}", "seconds_per_batch": dt,
             "codec_tokens_per_s": 7 * batch * cfg.n_frames / dt, "gemm_tflops": flops / dt / 1e12}
+
+
+def fp8_fast_path(dev, dtype, batch, cfg, sd32, texts, proms):
+    """BASELINE.json configs[4] on one GPU: e4m3 operands for the QKV / cross-query / fc1 projections and the 50-step
+    schedule (49 iterations).  Reported beside `value`, never inside it (the headline is the bf16 100-step config);
+    the reference has no such mode, so the quality number is id agreement with the 16-bit path on the same schedule."""
+    import dataclasses
+    from vall_e.vall_e import AR
+    fast = dataclasses.replace(cfg, timesteps=50)
+    m = AR.from_config(fast)
+    m.load_state_dict({k: v for k, v in sd32.items() if k != "time_emb.weight"}, strict=False)
+    m = m.to(dtype).to(dev)
+    out = {}
+    ids = {}
+    for name, fp8 in (("bf16_50_steps", False), ("fp8_50_steps", True)):
+        m.generate_audio(texts, proms, seed=1, fp8=fp8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2):
+            ids[name] = m.generate_audio(texts, proms, seed=7, fp8=fp8)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        out[name] = {"seconds_per_batch": dt, "codec_tokens_per_s": batch * cfg.n_frames / dt}
+    live = slice(0, cfg.n_frames)
+    out["id_agreement_fp8_vs_bf16"] = float((ids["bf16_50_steps"][:, live] == ids["fp8_50_steps"][:, live]).float().mean())
+    out["note"] = ("49 iterations (timesteps = 50), same synthetic weights except time_emb (random init for the shorter "
+                   "schedule); fp8 = e4m3 rows / channels with fp32 scales for norm1->QKV, norm2|22->cross q, norm3->fc1")
+    return out
 
 
 def cpu_baseline(cfg, sd32, texts, proms, n_iters):
@@ -254,6 +283,9 @@ def main():
             d3pm_s = ms_per_step * 1e-3
             result["nar_levels_1to7"]["all_8_levels_codec_tokens_per_s"] = (
                 8 * batch * cfg.n_frames / (d3pm_s + result["nar_levels_1to7"]["seconds_per_batch"]))
+        if world == 1 and not args.no_fp8 and args.config == "libritts" and dtype != torch.float32:
+            note("measuring the fp8 / 50-step fast path")
+            result["fp8_fast_path"] = fp8_fast_path(dev, dtype, batch, cfg, sd32, texts, proms)
         if world == 1 and args.cpu_steps > 0:
             note("timing the CPU port of the reference sampler")
             cpu_texts, cpu_proms = synth.make_inputs(cfg, 1, 1)

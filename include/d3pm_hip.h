@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-/* 2: + d3pm_ce_loss_rows, D3PM_FLAG_SEED_IN_HBM, tuning knobs 2..3, GEMM variant 5 (additions only) */
+/* 2: + d3pm_ce_loss_rows, the fp8 entry points (d3pm_*_fp8), D3PM_FLAG_SEED_IN_HBM, tuning knobs 2..3, GEMM variant 5
+ *    (additions only) */
 #define D3PM_ABI_VERSION 2
 
 enum { D3PM_F32 = 0, D3PM_F16 = 1, D3PM_BF16 = 2 };
