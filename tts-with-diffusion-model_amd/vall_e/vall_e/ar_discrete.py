@@ -242,6 +242,8 @@ class AR(nn.Module):
             x, frame_mask = self.canvas_init(B, n_frames)
             fl = flags | (_hip.FLAG_GREEDY if greedy else 0)
             use_graph = bool(graph)
+            if fp8 and (use_graph or (n_streams > 1 and not return_trace)):
+                raise ValueError("fp8=True runs on the single-stream eager loop only (no graph replay, no stream chunks)")
             use_graph = use_graph and not return_trace and not _hip.profiling()
             if use_graph:
                 kv_t, kv_p = smp.cond_kv(cond_text, cond_prompt)
