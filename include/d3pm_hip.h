@@ -303,11 +303,14 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
                       int M, int d, float eps, void *stream);
 
 /* Tuning knobs (process-wide; defaults are what bench.py measures).
- * D3PM_TUNE_GEMM_VARIANT: 0 = auto (default): latency schedule for M <= 1536 rows, throughput schedule otherwise;
+ * D3PM_TUNE_GEMM_VARIANT: 0 = auto (default): big-tile persistent schedule (192 x 256 or 96 x 512 tiles, eight waves,
+ *                             one workgroup per CU) when the shape divides into >= 200 such tiles that fill whole rounds
+ *                             of the 256 CUs, else latency schedule for M <= 1536 rows, 128 x 128 throughput schedule otherwise;
  *                         2 = always the throughput schedule (one LDS stage, 4 workgroups per CU; persistent over the
  *                             128 x 128 tiles when M and N are multiples of 128 and there are >= 512 tiles, else as 5);
  *                         3 = always the latency schedule (two stages, asm DMA prefetch);
- *                         5 = throughput schedule with one tile per workgroup (the non-persistent form of 2).
+ *                         5 = throughput schedule with one tile per workgroup (the non-persistent form of 2);
+ *                         6 / 7 = as auto, but only the 192 x 256 / only the 96 x 512 big tile is considered.
  *                         Results are bit-identical across schedules.
  * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention: 0 = auto (default: 2 when that still
  *                         gives >= 4 workgroups per CU, else 1), 1 or 2.

@@ -1,8 +1,10 @@
-"""Interleaved A/B of GEMM tuning knobs inside one process: medians over alternating repetitions."""
+"""Interleaved A/B of GEMM schedules inside one process: medians over alternating repetitions.
+variants: 2 = 128x128 persistent (round-1 default), 6 = 192x256 big tile, 7 = 96x512 big tile."""
 import math, statistics, sys, torch
 sys.path.insert(0, "tts-with-diffusion-model_amd")
 from vall_e.vall_e import _hip
 DEV, dtype = "cuda", torch.bfloat16
+VARIANTS = [int(v) for v in sys.argv[1:]] or [2, 6, 7]
 
 
 def timeit(f, n=10):
@@ -21,10 +23,18 @@ for name, M, N, K, act, res in shapes:
     b = torch.randn(N, device=DEV).to(dtype); y = torch.empty(M, N, device=DEV, dtype=dtype)
     r = torch.randn(M, N, device=DEV).to(dtype) if res else None
     f = lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=N)
-    res_t = {2: [], 5: []}
+    res_t = {v: [] for v in VARIANTS}
+    outs = {}
     for rep in range(7):
-        for variant in (2, 5):                      # persistent vs one tile per workgroup (swap in the knob under test)
+        for variant in VARIANTS:
             _hip.set_gemm_variant(variant)
             res_t[variant].append(timeit(f))
-    print(f"{name:9s} persistent {statistics.median(res_t[2]):7.1f} us | one tile {statistics.median(res_t[5]):7.1f} us", flush=True)
+            if rep == 0:
+                outs[variant] = y.clone()
+    same = all(torch.equal(outs[VARIANTS[0]], outs[v]) for v in VARIANTS)
+    line = f"{name:9s}"
+    for v in VARIANTS:
+        t = statistics.median(res_t[v])
+        line += f" | v{v}: {t:7.1f} us {2 * M * N * K / t / 1e6:7.1f} TF/s"
+    print(line + f" | bit-identical: {same}", flush=True)
 _hip.set_gemm_variant(0)

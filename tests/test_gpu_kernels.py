@@ -33,7 +33,8 @@ def gelu32(v):
     return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
 
 
-@pytest.fixture(params=[2, 3, 5], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency", 5: "gemm_one_tile"}[v])
+@pytest.fixture(params=[2, 3, 5, 6, 7], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency", 5: "gemm_one_tile",
+                                                       6: "gemm_big_192x256", 7: "gemm_big_96x512"}[v])
 def gemm_variant(request, built_lib):
     """Both schedules of the MFMA GEMM must pass the same numerics (auto selection is restored afterwards)."""
     from vall_e.vall_e import _hip
@@ -52,7 +53,8 @@ def attn_qg(request, built_lib):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,ldy", [(448, 512, 512, None), (1536, 1536, 512, None), (1536, 512, 2048, None),
-                                       (448, 1025, 512, 1032), (200, 96, 64, None), (448, 2048, 512, None)])
+                                       (448, 1025, 512, 1032), (200, 96, 64, None), (448, 2048, 512, None),
+                                       (49344, 512, 256, None), (576, 1024, 384, 1040)])
 def test_linear_mfma_vs_generic_vs_torch(gemm_variant, dtype, M, N, K, ldy):
     from vall_e.vall_e import _hip
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
@@ -111,6 +113,36 @@ def test_gemm_schedules_are_bit_identical(built_lib):
         outs.append(_hip.op_linear(x, w, b, act=1, family=_hip.FAMILY_MFMA).clone())
     _hip.set_gemm_variant(0)
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "r1", "r1r2", "r1mask", "nobias"])
+@pytest.mark.parametrize("M,N,K", [(9600, 1536, 512), (2496, 512, 2048), (192, 512, 256)])
+def test_gemm_big_tiles_match_one_tile_kernel(built_lib, dtype, epi, M, N, K):
+    """The big-tile persistent schedules (192 x 256 and 96 x 512 tiles, eight waves, d3pm_mfma_gemm_big.hip) against the
+    128 x 128 one-tile-per-workgroup kernel, bit for bit, for every epilogue: 300 / 300 tiles (a second tile for some
+    workgroups, stores in flight into it), a long-K single round, and the smallest legal shape (K = 4 k-steps)."""
+    from vall_e.vall_e import _hip
+    T = 96
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype).to(DEV)
+    b = None if epi == "nobias" else (torch.randn(N, generator=g) * 0.1).to(dtype).to(DEV)
+    r1 = torch.randn(M, N, generator=g).to(dtype).to(DEV) if epi.startswith("r1") else None
+    r2 = torch.randn(M, N, generator=g).to(dtype).to(DEV) if epi == "r1r2" else None
+    mask = (torch.rand(T, generator=g) < 0.8).to(torch.uint8).to(DEV) if epi == "r1mask" else None
+    outs = []
+    for v in (5, 6, 7):
+        _hip.set_gemm_variant(v)
+        for rep in range(2):            # twice: a race between the DMA pieces and the fragment reads would not repeat
+            outs.append(_hip.op_linear(x, w, b, act=1 if epi == "gelu" else 0, r1=r1, r2=r2, row_mask=mask, mask_period=T,
+                                       family=_hip.FAMILY_MFMA).clone())
+    _hip.set_gemm_variant(0)
+    for i, o in enumerate(outs[1:]):
+        assert torch.equal(outs[0], o), f"variant {(5, 5, 6, 6, 7, 7)[i + 1]} differs on {(outs[0] != o).float().mean().item():.2e} of the elements"
+    if epi in ("bias", "nobias"):
+        ref = x.float() @ w.float().T + (b.float() if b is not None else 0)
+        assert_close_lp(outs[0], ref, dtype, f"big tile reference {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

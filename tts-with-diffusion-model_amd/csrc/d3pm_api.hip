@@ -668,7 +668,7 @@ int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const vo
 }
 
 int d3pm_set_tuning(int knob, int value) {
-  if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || value == 2 || value == 3 || value == 5)) { set_gemm_variant(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || value == 2 || value == 3 || value == 5 || value == 6 || value == 7)) { set_gemm_variant(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && value >= 0 && value <= 2) { set_attn_qg(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && (value == 0 || value == 1)) { set_attn_pair_sequential(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_PERSIST_SLOTS && value >= 8 && value <= 4096 && value % 8 == 0) { set_gemm_persist_slots(value); return D3PM_OK; }

@@ -43,51 +43,13 @@
 // persistent schedule (17 % fewer L2 bytes, bit-identical, 51.2 vs 51.6 us on qkv in an interleaved A/B: no change).
 // M and N tails are handled by clamped loads and predicated stores; K must be a multiple of 64.
 #include "d3pm_kernels.h"
+#include "d3pm_mfma_tile.h"
 
 namespace d3pm {
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int ROW_BYTES = BK * 2;                       // 128 B per LDS row
+constexpr int BM = 128, BN = 128;
 constexpr int TILE_BYTES = BM * ROW_BYTES;              // 16 KiB per operand tile
-
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-template <typename T> __device__ __forceinline__ floatx4 mma(uint4 a, uint4 b, floatx4 c);
-template <> __device__ __forceinline__ floatx4 mma<f16>(uint4 a, uint4 b, floatx4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ floatx4 mma<bf16>(uint4 a, uint4 b, floatx4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// erf for the GELU epilogue: erf(x) = sign(x) (1 - 2^(-t P(t))), t = min(|x|, 3.95), P a degree-8 fit of
-// -log2(erfc(t))/t (fit error 2e-9, fp32 evaluation within 1.4 * 2^-24 absolute of the exact erf on [-6, 6]).  One
-// straight-line chain of 8 FMAs and one v_exp_f32 instead of libm's two-branch erff: the fc1 epilogue was VALU-bound
-// on erff (2500 of its 3400 vector instructions per wave, 60 of the 95 us of the kernel at 24576 x 2048).  What GELU
-// needs is absolute accuracy of erf at the 2^-24 grid -- the reference's own 1 + erf(x) cancels against that grid in
-// the negative tail -- and there this form is as close to torch's CPU gelu as torch's is to the exact function
-// (tools/fit_erf.py: fp16 7.6e-4 / bf16 9e-5 of N(0,1) inputs round differently, torch-vs-exact 6.2e-4 / 9e-5).
-// The generic (FMA) family keeps libm's erff: it is the numerical specification and the bit-exact native-shape path.
-__device__ __forceinline__ float erf_fit(float x) {
-  const float t = fminf(fabsf(x), 3.95f);
-  float p = -1.1604810424614698e-05f;
-  p = __builtin_fmaf(p, t, 0.00015296436322387308f);
-  p = __builtin_fmaf(p, t, -0.000848234398290515f);
-  p = __builtin_fmaf(p, t, 0.0022747856564819813f);
-  p = __builtin_fmaf(p, t, -8.480551332468167e-05f);
-  p = __builtin_fmaf(p, t, -0.027724476531147957f);
-  p = __builtin_fmaf(p, t, 0.1483079046010971f);
-  p = __builtin_fmaf(p, t, 0.9184429049491882f);
-  p = __builtin_fmaf(p, t, 1.6279072761535645f);
-  const float e = __builtin_amdgcn_exp2f(-(p * t));
-  return __builtin_copysignf(1.0f - e, x);
-}
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fit(v * 0.70710678118654752f)); }
 
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Remap the linear block
@@ -98,181 +60,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// Epilogue.  The MFMA leaves D[n = nt*16 + (lane>>4)*4 + r][m = mt*16 + (lane&15)] in a lane: 4 consecutive
-// columns of one row per (nt, mt), i.e. 8-byte stores that touch 32 contiguous bytes per row and instruction.
-// v_permlane16_swap between the accumulators of column blocks nt and nt+1 (odd 16-lane rows of the first operand
-// trade places with the even rows of the second) regroups them so that a lane owns 8 consecutive columns
-//   n = (nt + (g&1))*16 + (g>>1)*8 .. +7,   g = lane>>4,
-// after bias + activation (elementwise, so the order does not matter): residuals and the output then move as
-// 16-byte accesses, half the store instructions and 64 contiguous bytes per row and instruction (the store tail is
-// issue-bound, MI355X_MICROARCH.md constants table).  Values and rounding points are untouched -- the swap only
-// changes which lane finishes which element.
-// The swap is inline asm on purpose: with hipcc 7.2 the two-result __builtin_amdgcn_permlane16_swap loses its second
-// result once the operands are floats in an unrolled loop (both halves read the first output register; seen in the
-// .s of a 10-line kernel and as 50 % wrong columns on the GPU).  `s_nop 1` covers the VALU-write -> permlane-read
-// hazard the compiler cannot see inside the string; the operands are always produced by the bias add (VALU), never
-// directly by an MFMA.
-// Residual loads are branch-free (clamped addresses) and batched per row; only the stores are predicated.
-// EPI bits: 1 = exact-erf GELU, 2 = one residual (R1), 4 = two residuals (R1, R2), 8 = frame mask, 16 = ReLU, 32 = SiLU
-constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8, EPI_RELU = 16, EPI_SILU = 32;
-
-typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
-template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
-  typedef T pair __attribute__((ext_vector_type(2)));
-  return __builtin_bit_cast(uint32_t, pair{static_cast<T>(a), static_cast<T>(b)});
-}
-template <typename T> struct alignas(8) Pack4 { T v[4]; };
-template <typename T> struct alignas(16) Pack8 { T v[8]; };
-
-__device__ __forceinline__ void swap_rows16(float& a, float& b) {
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-
-template <typename T, int EPI, int NT = 4, int MT = 4, bool kInteriorOnly = false>
-__device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* __restrict__ bias, T* Y, int ldy,
-                                               const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                               int mask_period, int M, int N, int mw0, int nw0, int lane) {
-  static_assert(NT % 2 == 0, "column blocks are regrouped in pairs");
-  constexpr bool kGelu = EPI & EPI_GELU, kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
-  constexpr int NP = NT / 2;
-  const int g = lane >> 4;
-  const int nq = (g & 1) * 16 + (g >> 1) * 8;           // column of this lane's 8-group inside a 32-column pair
-  // bias in the MFMA layout (applied before the regrouping).  Loads are branch-free per lane -- clamped addresses,
-  // one batch, one wait: per-element predicated loads compile to sixteen serialized L2 round trips.
-  float bv[NT][4];
-  if (bias == nullptr) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[nt][r] = 0.f;
-  } else if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(bias) & 7) == 0) {
-    Pack4<T> pb[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nw0 + nt * 16 + g * 4;
-      pb[nt] = *reinterpret_cast<const Pack4<T>*>(bias + (n < N ? n : N - 4));
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[nt][r] = static_cast<float>(pb[nt].v[r]);   // columns >= N are never stored
-  } else {
-    T sb[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = nw0 + nt * 16 + g * 4 + r;
-        sb[nt][r] = bias[n < N ? n : N - 1];
-      }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[nt][r] = static_cast<float>(sb[nt][r]);
-  }
-  auto finish = [&](float (&v)[8], int np, int mt) {   // bias + activation in the MFMA layout, then the regrouping
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      v[r] = rn<T>(acc[2 * np + (r >> 2)][mt][r & 3] + bv[2 * np + (r >> 2)][r & 3]);
-      if (kGelu) v[r] = rn<T>(gelu_erf(v[r]));
-      if (EPI & EPI_RELU) v[r] = fmaxf(v[r], 0.f);
-      if (EPI & EPI_SILU) v[r] = rn<T>(v[r] / (1.0f + expf(-v[r])));
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) swap_rows16(v[r], v[4 + r]);
-  };
-  if (kInteriorOnly || (mw0 + MT * 16 <= M && nw0 + NT * 16 <= N)) {
-    // interior wave tile (wave-uniform test): no clamps or predicates, one 64-bit row pointer per operand that
-    // advances by 16 rows, column offsets as instruction immediates
-    const int m = mw0 + (lane & 15);
-    T* y = Y + static_cast<size_t>(m) * ldy + nw0 + nq;
-    const T* r1 = kR1 ? R1 + static_cast<size_t>(m) * ldr + nw0 + nq : nullptr;
-    const T* r2 = kR2 ? R2 + static_cast<size_t>(m) * ldr + nw0 + nq : nullptr;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const float mk = kMask ? (row_mask[(m + mt * 16) % mask_period] ? 1.f : 0.f) : 1.f;
-      Pack8<T> p1[NP], p2[NP];
-      if (kR1) {
-#pragma unroll
-        for (int np = 0; np < NP; ++np) {
-          p1[np] = *reinterpret_cast<const Pack8<T>*>(r1 + np * 32);
-          if (kR2) p2[np] = *reinterpret_cast<const Pack8<T>*>(r2 + np * 32);
-        }
-      }
-#pragma unroll
-      for (int np = 0; np < NP; ++np) {
-        float v[8];
-        finish(v, np, mt);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          if (kR1) {
-            float res = static_cast<float>(p1[np].v[r]);
-            if (kR2) res = rn<T>(res + static_cast<float>(p2[np].v[r]));
-            v[r] = rn<T>(res + v[r]);
-          }
-          if (kMask) v[r] *= mk;
-        }
-        *reinterpret_cast<uintx4*>(y + np * 32) =
-            uintx4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
-      }
-      y += static_cast<size_t>(16) * ldy;
-      if (kR1) r1 += static_cast<size_t>(16) * ldr;
-      if (kR2) r2 += static_cast<size_t>(16) * ldr;
-    }
-    return;
-  }
-  if constexpr (kInteriorOnly) return;   // the persistent schedule is only ever launched over whole tiles
-  const int n_last = N >= 8 ? N - 8 : 0;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = mw0 + mt * 16 + (lane & 15);
-    const int mc = m < M ? m : M - 1;
-    const float mk = kMask ? (row_mask[mc % mask_period] ? 1.f : 0.f) : 1.f;
-    Pack8<T> p1[NP], p2[NP];
-    if (kR1) {   // N % 8 == 0 is guaranteed by mfma_linear_supported when a residual is given
-#pragma unroll
-      for (int np = 0; np < NP; ++np) {
-        int nc = nw0 + np * 32 + nq;
-        nc = nc < n_last ? nc : n_last;
-        p1[np] = *reinterpret_cast<const Pack8<T>*>(R1 + static_cast<size_t>(mc) * ldr + nc);
-        if (kR2) p2[np] = *reinterpret_cast<const Pack8<T>*>(R2 + static_cast<size_t>(mc) * ldr + nc);
-      }
-    }
-#pragma unroll
-    for (int np = 0; np < NP; ++np) {
-      const int n = nw0 + np * 32 + nq;
-      float v[8];
-      finish(v, np, mt);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        if (kR1) {
-          float res = static_cast<float>(p1[np].v[r]);
-          if (kR2) res = rn<T>(res + static_cast<float>(p2[np].v[r]));
-          v[r] = rn<T>(res + v[r]);
-        }
-      }
-      if (m < M && n < N) {
-        T* y = Y + static_cast<size_t>(m) * ldy + n;
-        if (n + 7 < N) {
-          Pack8<T> o;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) o.v[r] = static_cast<T>(v[r] * mk);
-          *reinterpret_cast<Pack8<T>*>(y) = o;
-        } else {
-          for (int r = 0; r < 8 && n + r < N; ++r) y[r] = static_cast<T>(v[r] * mk);
-        }
-      }
-    }
-  }
-}
-
 
 // ---- throughput schedule: direct-to-LDS staging (global_load_lds_dwordx4) ---------------------------------
 // Each wave-instruction lands 1 KiB = 8 rows x 128 B linearly in LDS (wave-uniform base + lane*16), so the
 // XOR swizzle is applied to the per-lane SOURCE address (logical chunk = lane&7 ^ f(row)) and undone by the
 // same lds_off() on the fragment reads.  No staging VGPRs, no ds_write pass.
-typedef __attribute__((address_space(3))) void* lds_void;
-typedef const __attribute__((address_space(1))) void* glb_void;
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 4) void gemm_mfma_128_glds(const T* __restrict__ X, int ldx, const T* __restrict__ W,
@@ -347,17 +139,7 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128_glds(const T* __restrict
 }
 
 
-// ---- latency schedule: direct-to-LDS staging issued from inline asm, next tile in flight under the MFMAs ---
-// hipcc cannot tell an in-flight LDS-DMA from the LDS reads of the tile being computed and drains it
-// (vmcnt(0)) before the first ds_read; issuing the DMA from asm keeps it out of the compiler's counters, so
-// the wait is placed by hand: counted vmcnt (8 DMAs per wave per tile stay in flight), raw s_barrier.
-__device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
+// ---- latency schedule: direct-to-LDS staging issued from inline asm (glds16_asm), next tile in flight under the MFMAs ---
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_128_pf(const T* __restrict__ X, int ldx, const T* __restrict__ W,
@@ -454,13 +236,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128_pf(const T* __restrict__
 // interior wave tile are the youngest operations, everything older -- the DMA -- has landed).  Ragged edge tiles go
 // through gemm_mfma_128_glds in a second launch, so this kernel carries no clamps and no predicated epilogue.
 // DMA sources are a uniform tile base (SGPR pair) plus a tile-invariant 32-bit per-lane offset.
-__device__ __forceinline__ void glds16_asm_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory");
-}
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 4) void gemm_mfma_128_persist(const T* __restrict__ X, int ldx, const T* __restrict__ W,
@@ -572,19 +347,29 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
-static int g_gemm_variant = 0;       // 0 auto, 2 throughput (persistent over whole tiles), 3 latency, 5 throughput with one tile per workgroup
+// 0 auto, 2 throughput (128 x 128 persistent over whole tiles), 3 latency, 5 throughput with one 128 x 128 tile per workgroup,
+// 6 / 7 big tiles (192 x 256 / 96 x 512, d3pm_mfma_gemm_big.hip) wherever they apply, else as auto without big tiles
+static int g_gemm_variant = 0;
 static int g_persist_slots = 1024;   // resident workgroups of the persistent schedule: 4 per CU x 256 CUs
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_gemm_persist_slots(int v) { g_persist_slots = v; }
 
+int big_linear_tile(int dtype, const LinearArgs& a, int want);
+int big_linear(int dtype, const LinearArgs& a, int wm, hipStream_t s);
+
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   // All schedules accumulate in the same order, so the choice never changes a bit of the result.
   const bool ffn_act = a.act == ACT_RELU || a.act == ACT_SILU;
-  const bool latency = !ffn_act && (g_gemm_variant == 3 || (g_gemm_variant == 0 && a.M <= 1536));
+  if (g_gemm_variant == 0 || g_gemm_variant == 6 || g_gemm_variant == 7) {
+    const int wm = big_linear_tile(dtype, a, g_gemm_variant == 6 ? 2 : g_gemm_variant == 7 ? 1 : 0);
+    if (wm) return big_linear(dtype, a, wm, s);
+  }
+  const bool autosel = g_gemm_variant == 0 || g_gemm_variant == 6 || g_gemm_variant == 7;
+  const bool latency = !ffn_act && (g_gemm_variant == 3 || (autosel && a.M <= 1536));
   const int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
   // shapes made of whole tiles go through the persistent kernel once there are enough tiles to fill the chip twice
   // over (a ragged edge would need a second launch that costs more than persistence gains: measured on N = 1025)
-  const bool persist = !latency && !ffn_act && (g_gemm_variant == 0 || g_gemm_variant == 2) && a.M % BM == 0 &&
+  const bool persist = !latency && !ffn_act && (autosel || g_gemm_variant == 2) && a.M % BM == 0 &&
                        a.N % BN == 0 && static_cast<long long>(n_tiles) * m_tiles >= 2 * 256 &&
                        static_cast<long long>(BM) * a.ldx * 2 < (1ll << 31) && static_cast<long long>(BN) * a.K * 2 < (1ll << 31);
   const size_t lds = (latency ? 4 : 2) * TILE_BYTES;   // 64 KiB: two workgroups per CU; 32 KiB: four
