@@ -76,44 +76,71 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def pmc_traffic(kernel_class="gemm"):
-    """HBM-side bytes per launch of the dominant kernel from the most recent committed rocprofv3 PMC summary
-    (profiles/*pmc_traffic.json, produced by profiles/summarize_pmc.py from separate --pmc FETCH_SIZE /
-    --pmc WRITE_SIZE passes over this same script: counters cannot be collected from inside the timed run)."""
+def build_id() -> str:
+    """Identity of the kernel sources this process runs (sha1 over csrc/ and the C header): rocprofv3 PMC summaries
+    under profiles/ carry the id of the tree they were collected on, so a traffic figure is only ever reported beside
+    timings of the same build."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        data = json.load(open(files[-1]))
-        return data[kernel_class]["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
-    except (OSError, KeyError, ValueError):
-        return None, None
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "tts-with-diffusion-model_amd", "csrc", "*")) +
+                   [os.path.join(ROOT, "include", "d3pm_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def pmc_traffic(kernel_class="gemm"):
+    """HBM-side bytes per launch of a kernel class from the committed rocprofv3 PMC summary of THIS build
+    (profiles/*pmc_traffic.json, written by profiles/summarize_pmc.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE
+    passes over this same script: counters cannot be collected from inside the timed run).  A summary of another build
+    (its `_build_id` differs from build_id()) is not reported: returns (None, reason)."""
+    import glob
+    me = build_id()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            data = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if data.get("_build_id") == me and kernel_class in data:
+            return data[kernel_class]["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, f"no profiles/*pmc_traffic.json was collected on build {me}"
 
 
 def nar_stage(dev, dtype, batch, cfg, level0):
     """The step right after the D3PM path (reference __main__.py:36-38): the stock NAR model (registry size
     d=1024 / 16 heads / 12 layers) fills quantizer levels 1..7 for the same batch.  Reported beside, never inside,
-    `value` (the BASELINE.json metric counts the D3PM stage)."""
+    `value` (the BASELINE.json metric counts the D3PM stage).  Inputs are resident in HBM like the D3PM stage's output is
+    in the real pipeline; the stage is timed twice over the same repetitions -- host wall clock around a synchronise and
+    HIP events on the stream -- so that a host-bound run shows up as a gap between the two."""
     from vall_e.vall_e import NAR, synth
     ncfg = synth.NARConfig()
     nar = NAR(ncfg.n_tokens, ncfg.d_model, ncfg.n_heads, ncfg.n_layers)
     nar.load_state_dict(synth.make_nar_state_dict(ncfg, 0))
     nar = nar.to(dtype).to(dev)
     texts, proms = synth.make_inputs(cfg, batch, 1)
-    resps = [level0[b, : cfg.n_frames].clamp(max=ncfg.n_tokens - 1).reshape(-1, 1).cpu() for b in range(batch)]
-    nar(texts, proms, resps, seed=1)                       # warm-up
+    texts = [t.to(dev) for t in texts]
+    proms = [p.to(dev) for p in proms]
+    resps = [level0[b, : cfg.n_frames].clamp(max=ncfg.n_tokens - 1).reshape(-1, 1) for b in range(batch)]   # on the device
+    for i in range(2):
+        nar(texts, proms, resps, seed=i)                   # warm-up
     torch.cuda.synchronize()
+    reps = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    reps = 2
+    e0.record()
     for i in range(reps):
         full = nar(texts, proms, resps, seed=2 + i)
+    e1.record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    dt_ev = e0.elapsed_time(e1) * 1e-3 / reps
     assert full[0].shape == (cfg.n_frames, 8)
     rows = sum(len(t) + len(p) + len(r) + 2 for t, p, r in zip(texts, proms, resps))
     flops = 7.0 * rows * ncfg.n_layers * 24 * ncfg.d_model ** 2       # GEMM flops only (QKV, out, FFN), 7 levels
     return {"model": f"NAR d={ncfg.d_model} H={ncfg.n_heads} L={ncfg.n_layers}", "seconds_per_batch": dt,
+            "seconds_per_batch_hip_events": dt_ev, "repetitions": reps,
             "codec_tokens_per_s": 7 * batch * cfg.n_frames / dt, "gemm_tflops": flops / dt / 1e12}
 
 
@@ -222,14 +249,16 @@ def main():
         note(f"warmup {i + 1}/{args.warmup} done")
     fence()
     iters = args.profile_iters or (cfg.timesteps - 1)
-    if not args.no_kernel_events:
-        _hip.prof_enable(_hip.K_GEMM, args.steps * iters * (cfg.n_layers * 9 + 1) + 64)
+    if not args.no_kernel_events:     # every kernel class, launches inside the diffusion loop only, each 16th iteration
+        _hip.prof_enable(_hip.K_ALL, args.steps * (iters // 16 + 2) * (cfg.n_layers * 14 + 4) + 64)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    launches, gemm_ms, gemm_flops, gemm_bytes = _hip.prof_read()
+    per_class = {name: _hip.prof_read_class(k) for name, k in (("gemm", _hip.K_GEMM), ("attention", _hip.K_ATTN),
+                                                                  ("layernorm", _hip.K_LN), ("sample", _hip.K_SAMPLE))}
+    launches, gemm_ms, gemm_flops, gemm_bytes = per_class["gemm"]
     _hip.prof_disable()
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -255,16 +284,33 @@ def main():
     if rank == 0:
         key = args.dtype
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic("gemm") if args.config == "libritts" and batch == 32 else (None, None)
-        result["roofline"] = {"bound": "mfma", "kernel": "gemm_mfma (all DiT GEMM launches of the timed region)",
+        traffic, traffic_src = pmc_traffic("gemm") if args.config == "libritts" and batch == 32 else (None, "PMC passes cover the headline workload only")
+        result["roofline"] = {"bound": "mfma", "kernel": "gemm_mfma_* (the DiT projection / MLP / final GEMM launches inside the diffusion loop)",
                               "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[key], "unit": "TFLOP/s",
                               "frac": achieved / MFMA_PEAK_TFLOPS[key], "traffic": traffic,
                               "traffic_unit": "bytes/launch (L2 fabric-side, rocprofv3 PMC)", "traffic_source": traffic_src,
+                              "build_id": build_id(),
                               "algorithmic_bytes_per_launch": gemm_bytes / max(launches, 1),
                               "algorithmic_flops_per_launch": gemm_flops / max(launches, 1),
                               "launches_timed": launches, "avg_launch_us": gemm_ms * 1e3 / max(launches, 1),
-                              "timing": "HIP event pairs on the launch stream around every GEMM launch of each 16th "
-                                        "diffusion iteration of the timed region (all launches cost ~6 % of the step)"}
+                              "timing": "HIP event pairs on the launch stream around every launch of each 16th diffusion "
+                                        "iteration of the timed region (bracketing all launches costs ~6 % of the step)"}
+        table = {}
+        for name, (n, ms, fl, by) in per_class.items():
+            if n == 0:
+                continue
+            sec = ms * 1e-3
+            row = {"launches_timed": n, "avg_launch_us": ms * 1e3 / n, "share_of_timed_kernel_time": None,
+                   "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mb_per_launch": by / n / 1e6,
+                   "tflops": fl / sec / 1e12 if sec > 0 else 0.0, "gbs": by / sec / 1e9 if sec > 0 else 0.0}
+            bound = "mfma" if name in ("gemm", "attention") else "hbm"
+            row["bound"] = bound
+            row["frac_of_bound"] = (row["tflops"] / MFMA_PEAK_TFLOPS[key]) if bound == "mfma" else (row["gbs"] / HBM_PEAK_GBS)
+            table[name] = row
+        total_ms = sum(v[1] for v in per_class.values())
+        for name, row in table.items():
+            row["share_of_timed_kernel_time"] = per_class[name][1] / total_ms if total_ms > 0 else None
+        result["kernel_classes"] = table
         whole = algorithmic_flops_per_step(cfg, batch) * iters / (cfg.timesteps - 1) / (ms_per_step * 1e-3) / 1e12
         result["whole_step_tflops"] = whole
         if not args.no_latency:

@@ -310,24 +310,36 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *                             128 x 128 tiles when M and N are multiples of 128 and there are >= 512 tiles, else as 5);
  *                         3 = always the latency schedule (two stages, asm DMA prefetch);
  *                         5 = throughput schedule with one tile per workgroup (the non-persistent form of 2);
- *                         6 / 7 = as auto, but only the 192 x 256 / only the 96 x 512 big tile is considered.
+ *                         6 / 7 / 8 = as auto, but only the 192 x 256 / 96 x 512 / 192 x 128 (two 4-wave workgroups per CU) big
+ *                             tile is considered, for any shape made of whole tiles.
  *                         Results are bit-identical across schedules.
  * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention: 0 = auto (default: 2 when that still
  *                         gives >= 4 workgroups per CU, else 1), 1 or 2.
  * D3PM_TUNE_ATTN_PAIR_SEQUENTIAL: 1 (default) = a paired attention launch (text + prompt cross-attention) runs both
  *                         problems in every workgroup, one after the other; 0 = the second half of the grid takes problem 2.
  * D3PM_TUNE_GEMM_PERSIST_SLOTS: resident workgroups of the persistent throughput schedule, a multiple of 8
- *                         (default 1024 = 4 per CU). */
+ *                         (default 1024 = 4 per CU).
+ * D3PM_TUNE_GEMM_BIG_MODE: schedule of the big-tile GEMM: 1 (default) / 0 = hand-placed / compiler-placed fragment reads (same
+ *                         results);
+ *                         >= 16 = timing-only ablation builds for tests/ab_gemm.py (WRONG results; bits: 16 no DMA, 32 no
+ *                         MFMA, 64 no barriers, 128 no LDS reads, 256 clock stamp for d3pm_debug_gemm_clock). */
 enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2,
-       D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3 };
+       D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4 };
 int d3pm_set_tuning(int knob, int value);
+/* Diagnostic: after a big-tile GEMM launched with D3PM_TUNE_GEMM_BIG_MODE bit 8 set (and a device synchronisation),
+ * {shader clocks, 100 MHz reference ticks} that workgroup 0 spent in the kernel: clocks / ticks * 100 MHz = the clock the
+ * chip held under that load (MI355X_MICROARCH.md "DVFS give-back" item 6).  No output of the kernel depends on it. */
+int d3pm_debug_gemm_clock(unsigned long long* clocks_and_ticks);
 
 /* Timing hooks for bench.py's roofline object: when enabled, every launch of the kernel class
- * `kclass` (D3PM_K_*) inside d3pm_sample_loop is bracketed by a hipEvent pair on `stream` (in every 16th
- * diffusion iteration only, so that the event pairs do not perturb the timed region they measure);
- * d3pm_prof_read synchronises those events and returns launch count and total milliseconds. */
+ * `kclass` (D3PM_K_*; D3PM_K_COUNT = every class) made INSIDE d3pm_sample_loop is bracketed by a hipEvent pair on
+ * `stream` (in every 16th diffusion iteration only, so that the event pairs do not perturb the timed region they
+ * measure; launches outside the loop -- condition encoders, cond-K/V projections -- are never bracketed).
+ * d3pm_prof_read_class synchronises the events of one class and returns its launch count, total milliseconds and the
+ * algorithmic flops / bytes of those launches; d3pm_prof_read returns the sums over the classes and resets. */
 enum { D3PM_K_GEMM = 0, D3PM_K_ATTN = 1, D3PM_K_SAMPLE = 2, D3PM_K_LN = 3, D3PM_K_COUNT = 4 };
 int d3pm_prof_enable(int kclass, int max_events);
+int d3pm_prof_read_class(int kclass, int *launches, double *total_ms, double *flops, double *bytes);
 int d3pm_prof_read(int *launches, double *total_ms, double *flops, double *bytes);
 int d3pm_prof_disable(void);
 

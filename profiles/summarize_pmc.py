@@ -40,6 +40,13 @@ def main():
         out[cls] = {"launches_profiled": fetch[cls][0], "fetch_bytes_per_launch_raw": f,
                     "fetch_bytes_per_launch_corrected": 2.0 * f, "write_bytes_per_launch": w,
                     "traffic_bytes_per_launch": 2.0 * f + w}
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out["_build_id"] = bench.build_id()          # bench.py only reports this traffic beside timings of the same build
     out["_method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1 "
                       "--warmup 0 --profile-iters 3 (B=32 libritts bf16); KiB -> bytes; FETCH_SIZE x2 (gfx950)")
     json.dump(out, sys.stdout, indent=1)

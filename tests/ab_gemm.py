@@ -1,10 +1,11 @@
 """Interleaved A/B of GEMM schedules inside one process: medians over alternating repetitions.
-variants: 2 = 128x128 persistent (round-1 default), 6 = 192x256 big tile, 7 = 96x512 big tile."""
+arguments: <variant>[m<big mode>] ...   variants: 2 = 128x128 persistent (round-1 default), 6 = 192x256 big tile,
+7 = 96x512 big tile; big modes: 0 compiler-placed reads, 1 hand-placed reads, 16 / 17 / 32 timing-only ablations."""
 import math, statistics, sys, torch
 sys.path.insert(0, "tts-with-diffusion-model_amd")
 from vall_e.vall_e import _hip
 DEV, dtype = "cuda", torch.bfloat16
-VARIANTS = [int(v) for v in sys.argv[1:]] or [2, 6, 7]
+ARMS = [(int(a.split("m")[0]), int(a.split("m")[1]) if "m" in a else 1) for a in (sys.argv[1:] or ["2", "6", "7", "8", "0"])]
 
 
 def timeit(f, n=10):
@@ -23,18 +24,21 @@ for name, M, N, K, act, res in shapes:
     b = torch.randn(N, device=DEV).to(dtype); y = torch.empty(M, N, device=DEV, dtype=dtype)
     r = torch.randn(M, N, device=DEV).to(dtype) if res else None
     f = lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=N)
-    res_t = {v: [] for v in VARIANTS}
-    outs = {}
+    res_t = {a: [] for a in ARMS}
+    outs, clocks = {}, {}
     for rep in range(7):
-        for variant in VARIANTS:
-            _hip.set_gemm_variant(variant)
-            res_t[variant].append(timeit(f))
-            if rep == 0:
-                outs[variant] = y.clone()
-    same = all(torch.equal(outs[VARIANTS[0]], outs[v]) for v in VARIANTS)
+        for arm in ARMS:
+            _hip.set_gemm_variant(arm[0]); _hip.set_gemm_big_mode(arm[1])
+            res_t[arm].append(timeit(f))
+            if arm[1] & 256 and rep == 6:
+                clocks[arm] = _hip.gemm_clock_ghz()
+            if rep == 0 and arm[1] < 16:
+                outs[arm] = y.clone()
+    ref = next(iter(outs.values()))
+    same = all(torch.equal(ref, o) for o in outs.values())
     line = f"{name:9s}"
-    for v in VARIANTS:
-        t = statistics.median(res_t[v])
-        line += f" | v{v}: {t:7.1f} us {2 * M * N * K / t / 1e6:7.1f} TF/s"
+    for arm in ARMS:
+        t = statistics.median(res_t[arm])
+        line += f" | v{arm[0]}m{arm[1]}: {t:6.1f} us {2 * M * N * K / t / 1e6:6.0f} TF/s" + (f" @{clocks[arm]:.2f} GHz" if arm in clocks else "")
     print(line + f" | bit-identical: {same}", flush=True)
-_hip.set_gemm_variant(0)
+_hip.set_gemm_variant(0); _hip.set_gemm_big_mode(1)

@@ -33,3 +33,16 @@ def same_platform_as_golden() -> bool:
             return f.read().strip() == fingerprint()
     except OSError:
         return False
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _parity_report_file():
+    """The numbers the -m gpu tests measured (tests/util.py:REPORT) -> gpurun_out/parity_report.json."""
+    yield
+    import json
+    from util import REPORT
+    if REPORT:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)

@@ -1,4 +1,5 @@
 # PMC deep-dive on the GEMM / attention micro-kernels (separate passes, counters only)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc2
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $GRAFT_REPO_ROOT/gpurun_out/pmc2/counters.txt 2>&1

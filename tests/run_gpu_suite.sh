@@ -1,4 +1,5 @@
 # GPU-box driver: kernel numerics, parity, smoke, bench, rocprof.  Usage: bash tests/run_gpu_suite.sh [stage...]
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 STAGES="${@:-kernels parity smoke bench prof}"
 ok=1

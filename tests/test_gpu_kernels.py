@@ -33,8 +33,8 @@ def gelu32(v):
     return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
 
 
-@pytest.fixture(params=[2, 3, 5, 6, 7], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency", 5: "gemm_one_tile",
-                                                       6: "gemm_big_192x256", 7: "gemm_big_96x512"}[v])
+@pytest.fixture(params=[2, 3, 5, 6, 7, 8], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency", 5: "gemm_one_tile",
+                                                          6: "gemm_big_192x256", 7: "gemm_big_96x512", 8: "gemm_big_192x128"}[v])
 def gemm_variant(request, built_lib):
     """Both schedules of the MFMA GEMM must pass the same numerics (auto selection is restored afterwards)."""
     from vall_e.vall_e import _hip
@@ -119,7 +119,8 @@ def test_gemm_schedules_are_bit_identical(built_lib):
 @pytest.mark.parametrize("epi", ["bias", "gelu", "r1", "r1r2", "r1mask", "nobias"])
 @pytest.mark.parametrize("M,N,K", [(9600, 1536, 512), (2496, 512, 2048), (192, 512, 256)])
 def test_gemm_big_tiles_match_one_tile_kernel(built_lib, dtype, epi, M, N, K):
-    """The big-tile persistent schedules (192 x 256 and 96 x 512 tiles, eight waves, d3pm_mfma_gemm_big.hip) against the
+    """The big-tile persistent schedules (192 x 256 / 96 x 512 tiles of eight waves, 192 x 128 tiles of four; compiler- and
+    hand-placed fragment reads; d3pm_mfma_gemm_big.hip) against the
     128 x 128 one-tile-per-workgroup kernel, bit for bit, for every epilogue: 300 / 300 tiles (a second tile for some
     workgroups, stores in flight into it), a long-K single round, and the smallest legal shape (K = 4 k-steps)."""
     from vall_e.vall_e import _hip
@@ -131,15 +132,19 @@ def test_gemm_big_tiles_match_one_tile_kernel(built_lib, dtype, epi, M, N, K):
     r1 = torch.randn(M, N, generator=g).to(dtype).to(DEV) if epi.startswith("r1") else None
     r2 = torch.randn(M, N, generator=g).to(dtype).to(DEV) if epi == "r1r2" else None
     mask = (torch.rand(T, generator=g) < 0.8).to(torch.uint8).to(DEV) if epi == "r1mask" else None
-    outs = []
-    for v in (5, 6, 7):
-        _hip.set_gemm_variant(v)
-        for rep in range(2):            # twice: a race between the DMA pieces and the fragment reads would not repeat
-            outs.append(_hip.op_linear(x, w, b, act=1 if epi == "gelu" else 0, r1=r1, r2=r2, row_mask=mask, mask_period=T,
-                                       family=_hip.FAMILY_MFMA).clone())
-    _hip.set_gemm_variant(0)
+    outs, arms = [], [(5, 0), (6, 0), (6, 1), (7, 0), (7, 1), (8, 0), (8, 1)]
+    try:
+        for v, mode in arms:
+            _hip.set_gemm_variant(v)
+            _hip.set_gemm_big_mode(mode)
+            for rep in range(2):        # twice: a race between the DMA pieces and the fragment reads would not repeat
+                outs.append(_hip.op_linear(x, w, b, act=1 if epi == "gelu" else 0, r1=r1, r2=r2, row_mask=mask, mask_period=T,
+                                           family=_hip.FAMILY_MFMA).clone())
+    finally:
+        _hip.set_gemm_variant(0)
+        _hip.set_gemm_big_mode(1)
     for i, o in enumerate(outs[1:]):
-        assert torch.equal(outs[0], o), f"variant {(5, 5, 6, 6, 7, 7)[i + 1]} differs on {(outs[0] != o).float().mean().item():.2e} of the elements"
+        assert torch.equal(outs[0], o), f"arm {arms[(i + 1) // 2]} differs on {(outs[0] != o).float().mean().item():.2e} of the elements"
     if epi in ("bias", "nobias"):
         ref = x.float() @ w.float().T + (b.float() if b is not None else 0)
         assert_close_lp(outs[0], ref, dtype, f"big tile reference {M}x{N}x{K}")

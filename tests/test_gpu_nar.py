@@ -64,7 +64,7 @@ def test_nar_mfma_family_and_batch_independence(built_lib):
     texts, proms, resps = synth.make_nar_inputs(3, 2, t_text=(20, 50), t_prom=(100, 225), t_resp=(300, 750))
     _, lg, lens, t_max = m(texts, proms, resps, return_logits_level=0, greedy=True)
     run = m.runner(t_max)
-    lens_d, text, prom, resp, _ = m._pack(texts, proms, resps)
+    lens_d, text, prom, resp, _, _ = m._pack(texts, proms, resps)
     lg_gen = run.level(lens_d, text, prom, resp, t_max, 0, 0.2, 0, flags=_hip.FLAG_FORCE_GENERIC | _hip.FLAG_GREEDY,
                        want_logits=True)
     for b in range(3):

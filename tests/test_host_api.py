@@ -124,3 +124,17 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace(
                     "oracle/philox.py", ""), f
+
+
+def test_wrapper_rejects_tensors_the_c_side_would_overrun():
+    """The C ABI derives every extent from the shape struct; the Python wrappers must refuse a tensor of another shape,
+    dtype or layout instead of handing its pointer over."""
+    import torch
+    from vall_e.vall_e import _hip
+    dev = torch.device("cpu")
+    ok = torch.zeros(2, 448, dtype=torch.int32)
+    _hip._require(ok, "x_t", (2, 448), (torch.int32,), dev)
+    for bad, why in ((torch.zeros(2, 300, dtype=torch.int32), "width"), (torch.zeros(2, 448, dtype=torch.int64), "dtype"),
+                     (torch.zeros(448, 2, dtype=torch.int32).t(), "layout"), ([1, 2], "type")):
+        with pytest.raises(_hip.D3PMError):
+            _hip._require(bad, "x_t", (2, 448), (torch.int32,), dev)

@@ -5,6 +5,7 @@ import numpy as np
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REPORT = {}      # measured parity numbers of a GPU run; conftest.py writes them to gpurun_out/parity_report.json
 
 
 def load(name):

@@ -29,15 +29,20 @@ void set_gemm_variant(int v);
 void set_gemm_persist_slots(int v);
 void set_attn_pair_sequential(int v);
 void set_attn_qg(int v);
+void set_big_gemm_mode(int v);
+int read_big_gemm_stamp(unsigned long long* out);
 
 // ---- profiling hooks (bench.py roofline object) ----------------------------------------------
+// Only launches made from inside d3pm_sample_loop are ever bracketed (sample_now is false outside it): the condition
+// encoders and the cond-K/V projections run once per utterance and are not part of any class's per-launch figures.
 struct Prof {
-  int kclass = -1;
-  std::vector<hipEvent_t> ev;   // pairs
+  int kclass = -1;                // -1 off, D3PM_K_* one class, D3PM_K_COUNT every class
+  std::vector<hipEvent_t> ev;     // pairs
+  std::vector<int> cls;           // class of pair i
   int used = 0;
-  double flops = 0, bytes = 0;
+  double flops[D3PM_K_COUNT] = {}, bytes[D3PM_K_COUNT] = {};
   int stride = 16;       // only the iterations with t % stride == 0 are bracketed (event pairs cost ~3 us each: all launches 6 % of the step, every 8th 2.5 %)
-  bool sample_now = true;
+  bool sample_now = false;
 };
 static Prof g_prof;
 
@@ -45,11 +50,13 @@ struct ProfScope {
   bool on;
   hipStream_t s;
   ProfScope(int kclass, hipStream_t st, double flops, double bytes) : s(st) {
-    on = g_prof.kclass == kclass && g_prof.sample_now && g_prof.used + 2 <= static_cast<int>(g_prof.ev.size());
+    on = (g_prof.kclass == kclass || g_prof.kclass == D3PM_K_COUNT) && g_prof.sample_now &&
+         g_prof.used + 2 <= static_cast<int>(g_prof.ev.size());
     if (on) {
       (void)hipEventRecord(g_prof.ev[g_prof.used], s);
-      g_prof.flops += flops;
-      g_prof.bytes += bytes;
+      g_prof.cls[g_prof.used / 2] = kclass;
+      g_prof.flops[kclass] += flops;
+      g_prof.bytes[kclass] += bytes;
     }
   }
   ~ProfScope() {
@@ -64,7 +71,8 @@ struct ProfScope {
 static int run_linear(int dtype, const LinearArgs& a, uint32_t flags, hipStream_t s) {
   const size_t es = dtype_size(dtype);
   ProfScope p(D3PM_K_GEMM, s, 2.0 * a.M * a.N * a.K,
-              es * (static_cast<double>(a.M) * a.K + static_cast<double>(a.N) * a.K + static_cast<double>(a.M) * a.N));
+              es * (static_cast<double>(a.M) * a.K + static_cast<double>(a.N) * a.K +
+                    static_cast<double>(a.M) * a.N * (1 + (a.R1 ? 1 : 0) + (a.R2 ? 1 : 0))));
   if (!(flags & D3PM_FLAG_FORCE_GENERIC) && mfma_linear_supported(dtype, a)) return mfma_linear(dtype, a, s);
   return generic_linear(dtype, a, s);
 }
@@ -142,8 +150,12 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
   const int n = batch * T;
   // fp8 fast path (BASELINE.json configs[4]): the three LayerNorm-fed K = d projections take e4m3 operands; the e4m3 rows
   // and their scales live where the 16-bit LayerNorm outputs would (ws.h | ws.h2 are adjacent: 2 n d 2 bytes)
-  const bool use8 = f8 != nullptr && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && fp8_linear_supported(dt, n, 3 * d, d, d, 3 * d) &&
-                    ws.h2 == at(ws.h, static_cast<size_t>(n) * d, dtype_size(dt));
+  const bool use8 = f8 != nullptr;
+  if (use8) {   // the *_fp8 entry points never fall back to the 16-bit kernels silently: a number labelled fp8 is fp8
+    D3PM_REQUIRE(!(flags & D3PM_FLAG_FORCE_GENERIC), D3PM_E_ARG, "fp8 fast path: D3PM_FLAG_FORCE_GENERIC selects the 16-bit generic kernels");
+    D3PM_REQUIRE(d == 512 && fp8_linear_supported(dt, n, 3 * d, d, d, 3 * d) && ws.h2 == at(ws.h, static_cast<size_t>(n) * d, dtype_size(dt)),
+                 D3PM_E_SHAPE, "fp8 fast path needs d_model = 512, a 16-bit model dtype and batch * canvas (%d) a multiple of 128", n);
+  }
   uint8_t* x8 = reinterpret_cast<uint8_t*>(ws.h);
   float* sx8 = reinterpret_cast<float*>(ws.h2);     // 2 n floats at most (n d 2 bytes available)
   const size_t es = dtype_size(dt);
@@ -479,7 +491,7 @@ static int sample_loop_impl(const d3pm_shape* sh, const d3pm_weights* w, int bat
       D3PM_TRY(posterior_sample(a, s));
     }
   }
-  g_prof.sample_now = true;
+  g_prof.sample_now = false;
   return D3PM_OK;
 }
 
@@ -668,45 +680,73 @@ int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const vo
 }
 
 int d3pm_set_tuning(int knob, int value) {
-  if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || value == 2 || value == 3 || value == 5 || value == 6 || value == 7)) { set_gemm_variant(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || value == 2 || value == 3 || value == 5 || (value >= 6 && value <= 8))) { set_gemm_variant(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && value >= 0 && value <= 2) { set_attn_qg(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && (value == 0 || value == 1)) { set_attn_pair_sequential(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465)) { set_big_gemm_mode(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_PERSIST_SLOTS && value >= 8 && value <= 4096 && value % 8 == 0) { set_gemm_persist_slots(value); return D3PM_OK; }
   set_error("d3pm_set_tuning: unknown knob %d / value %d", knob, value);
   return D3PM_E_ARG;
 }
 
+int d3pm_debug_gemm_clock(unsigned long long* clocks_and_ticks) {
+  D3PM_REQUIRE(clocks_and_ticks, D3PM_E_ARG, "d3pm_debug_gemm_clock: null pointer");
+  return read_big_gemm_stamp(clocks_and_ticks);
+}
+
 int d3pm_prof_enable(int kclass, int max_events) {
-  D3PM_REQUIRE(kclass >= 0 && kclass < D3PM_K_COUNT && max_events > 0, D3PM_E_ARG, "d3pm_prof_enable: bad arguments");
+  D3PM_REQUIRE(kclass >= 0 && kclass <= D3PM_K_COUNT && max_events > 0, D3PM_E_ARG, "d3pm_prof_enable: bad arguments");
   d3pm_prof_disable();
   g_prof.ev.resize(static_cast<size_t>(max_events) * 2);
+  g_prof.cls.assign(static_cast<size_t>(max_events), -1);
   for (auto& e : g_prof.ev) D3PM_CHECK_HIP(hipEventCreate(&e));
   g_prof.kclass = kclass;
   g_prof.used = 0;
-  g_prof.flops = g_prof.bytes = 0;
+  for (int c = 0; c < D3PM_K_COUNT; ++c) g_prof.flops[c] = g_prof.bytes[c] = 0;
   return D3PM_OK;
 }
 
-int d3pm_prof_read(int* launches, double* total_ms, double* flops, double* bytes) {
+int d3pm_prof_read_class(int kclass, int* launches, double* total_ms, double* flops, double* bytes) {
+  D3PM_REQUIRE(kclass >= 0 && kclass < D3PM_K_COUNT, D3PM_E_ARG, "d3pm_prof_read_class: bad class");
   double ms = 0;
+  int n = 0;
   for (int i = 0; i + 1 < g_prof.used; i += 2) {
+    if (g_prof.cls[i / 2] != kclass) continue;
     D3PM_CHECK_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
     float m = 0;
     D3PM_CHECK_HIP(hipEventElapsedTime(&m, g_prof.ev[i], g_prof.ev[i + 1]));
     ms += m;
+    ++n;
   }
-  if (launches) *launches = g_prof.used / 2;
+  if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
-  if (flops) *flops = g_prof.flops;
-  if (bytes) *bytes = g_prof.bytes;
+  if (flops) *flops = g_prof.flops[kclass];
+  if (bytes) *bytes = g_prof.bytes[kclass];
+  return D3PM_OK;
+}
+
+int d3pm_prof_read(int* launches, double* total_ms, double* flops, double* bytes) {
+  int n = 0;
+  double ms = 0, fl = 0, by = 0;
+  for (int c = 0; c < D3PM_K_COUNT; ++c) {
+    int nc = 0;
+    double mc = 0, fc = 0, bc = 0;
+    D3PM_TRY(d3pm_prof_read_class(c, &nc, &mc, &fc, &bc));
+    n += nc; ms += mc; fl += fc; by += bc;
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
   g_prof.used = 0;
-  g_prof.flops = g_prof.bytes = 0;
+  for (int c = 0; c < D3PM_K_COUNT; ++c) g_prof.flops[c] = g_prof.bytes[c] = 0;
   return D3PM_OK;
 }
 
 int d3pm_prof_disable(void) {
   for (auto& e : g_prof.ev) (void)hipEventDestroy(e);
   g_prof.ev.clear();
+  g_prof.cls.clear();
   g_prof.kclass = -1;
   g_prof.used = 0;
   return D3PM_OK;

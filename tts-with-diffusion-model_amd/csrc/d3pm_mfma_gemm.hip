@@ -348,23 +348,23 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
 }
 
 // 0 auto, 2 throughput (128 x 128 persistent over whole tiles), 3 latency, 5 throughput with one 128 x 128 tile per workgroup,
-// 6 / 7 big tiles (192 x 256 / 96 x 512, d3pm_mfma_gemm_big.hip) wherever they apply, else as auto without big tiles
+// 6 / 7 / 8 big tiles (192 x 256 / 96 x 512 / 192 x 128, d3pm_mfma_gemm_big.hip) wherever they apply, else as auto without big tiles
 static int g_gemm_variant = 0;
 static int g_persist_slots = 1024;   // resident workgroups of the persistent schedule: 4 per CU x 256 CUs
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_gemm_persist_slots(int v) { g_persist_slots = v; }
 
 int big_linear_tile(int dtype, const LinearArgs& a, int want);
-int big_linear(int dtype, const LinearArgs& a, int wm, hipStream_t s);
+int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s);
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   // All schedules accumulate in the same order, so the choice never changes a bit of the result.
   const bool ffn_act = a.act == ACT_RELU || a.act == ACT_SILU;
-  if (g_gemm_variant == 0 || g_gemm_variant == 6 || g_gemm_variant == 7) {
-    const int wm = big_linear_tile(dtype, a, g_gemm_variant == 6 ? 2 : g_gemm_variant == 7 ? 1 : 0);
-    if (wm) return big_linear(dtype, a, wm, s);
+  const bool autosel = g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 8);
+  if (autosel) {
+    const int id = big_linear_tile(dtype, a, g_gemm_variant == 6 ? 2 : g_gemm_variant == 7 ? 1 : g_gemm_variant == 8 ? 3 : 0);
+    if (id) return big_linear(dtype, a, id, s);
   }
-  const bool autosel = g_gemm_variant == 0 || g_gemm_variant == 6 || g_gemm_variant == 7;
   const bool latency = !ffn_act && (g_gemm_variant == 3 || (autosel && a.M <= 1536));
   const int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
   // shapes made of whole tiles go through the persistent kernel once there are enough tiles to fill the chip twice

@@ -27,18 +27,56 @@
 namespace d3pm {
 namespace {
 
-template <typename T, int EPI, int WM>
-__global__ __launch_bounds__(512, 2) void gemm_mfma_big(const T* __restrict__ X, int ldx, const T* __restrict__ W,
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// one 16-byte fragment read whose completion is waited for by hand (lds_wait): hipcc would otherwise sink each read
+// down to the instruction before its first use (it minimises registers), which exposes the LDS latency in every group
+__device__ __forceinline__ void lds_read16(uintx4& dst, uint32_t addr, int off) {   // off: a constant after inlining
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+}
+// wait until at most N of this wave's LDS reads are outstanding; the "+v" operands are the fragments this makes valid,
+// so that no MFMA that consumes them can be scheduled above the wait
+template <int N> __device__ __forceinline__ void lds_wait(uintx4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lds_wait(uintx4& a, uintx4& b, uintx4& c, uintx4& d, uintx4& e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+}
+// DMA piece without the M0 save / restore of glds16_asm_s.  M0 is a reserved register that hipcc only writes right in
+// front of its own M0-reading instructions (LDS-DMA builtins, s_movrel, GWS), and gemm_mfma_big contains none of those
+// (checked in the .s: no m0 outside these statements), so the value left behind is never observed.
+__device__ __forceinline__ void glds16_m0(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// MODE: bit 0 = hand-scheduled fragment reads (asm, counted lgkmcnt); the other bits are timing-only ablations (WRONG
+// results): 16 = no DMA pieces in the k-loop, 32 = no fragment reads / MFMAs, 64 = no waits / barriers, 128 = the MFMAs
+// take their operands from registers (no LDS reads)
+__device__ unsigned long long g_big_stamp[4];   // MODE bit 8: {shader clocks, 100 MHz ticks} of block 0 (clock under load)
+
+template <typename T, int EPI, int WM, int WN, int MODE>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                         const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                         const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                         int mask_period, int M, int N, int K, int n_tiles,
                                                         int tiles_total) {
-  constexpr int WN = 8 / WM, TM = 96 * WM, TN = 64 * WN;
+  constexpr int NW = WM * WN, TM = 96 * WM, TN = 64 * WN;   // 8 waves: one workgroup per CU; 4 waves: two
   constexpr int XD = TM / 8, WD = TN / 8;              // 1-KiB DMA pieces (8 rows x 128 B) per k-step and operand
-  constexpr int XPW = (XD + 7) / 8, WPW = WD / 8;      // pieces per wave
-  constexpr int NDMA = XPW + WPW;                      // 7 (192 x 256) or 10 (96 x 512; waves 4..7 repeat an X piece)
+  constexpr int XPW = (XD + NW - 1) / NW, WPW = WD / NW;   // pieces per wave
+  constexpr int NDMA = XPW + WPW;                      // 7 (192 x 256), 10 (96 x 512: waves 4..7 repeat an X piece), 10 (192 x 128)
+  static_assert(NW % 2 == 0 && WD % NW == 0 && (XD % NW == 0 || (XD % NW) % 2 == 0), "piece distribution keeps the parity of the wave");
   constexpr int X_BYTES = TM * ROW_BYTES, STAGE = (TM + TN) * ROW_BYTES;
   static_assert(NDMA <= 12, "one DMA piece per group of four MFMAs");
+  constexpr bool kHand = (MODE & 1) != 0;
+  constexpr int ABL = (MODE >> 4) & 3;
+  constexpr bool kNoSync = (MODE & 64) != 0, kNoReads = (MODE & 128) != 0, kStamp = (MODE & 256) != 0;
+  constexpr bool kPrioYoung = (MODE & 2) != 0, kPrioMfma = (MODE & 4) != 0;
+  unsigned long long stamp_c = 0, stamp_r = 0;
+  if constexpr (kStamp) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,19 +88,21 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_big(const T* __restrict__ X,
   int t = blockIdx.x >> 3;
   if (t >= cnt) return;                                              // block-uniform
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
-  // DMA piece j of an operand tile = rows 8j .. 8j+7; a wave takes pieces j = wave + 8p, so the swizzle key
+  // DMA piece j of an operand tile = rows 8j .. 8j+7; a wave takes pieces j = wave + NW p, so the swizzle key
   // (row >> 1) & 7 = (4 (j & 1) + (lane >> 4)) & 7 is the same for all of its pieces: one per-lane offset per operand
   const int lrow = lane >> 3, logical = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
   const uint32_t ox = static_cast<uint32_t>(lrow * ldx + logical * 8) * 2u;
   const uint32_t ow = static_cast<uint32_t>(lrow * K + logical * 8) * 2u;
   auto dma = [&](int p, const T* px, const T* pw, uint32_t stage) __attribute__((always_inline)) {   // p: unrolled constant
     if (p < XPW) {
-      int j = wave + 8 * p;
-      if (XD % 8 != 0 && j >= XD) j = (XD / 8) * 8 + (wave & 3);     // same parity as `wave`: a harmless repeat
-      glds16_asm_s(px + static_cast<size_t>(8 * j) * ldx, ox, stage + j * 1024);
+      int j = wave + NW * p;
+      if (XD % NW != 0 && j >= XD) j = (XD / NW) * NW + wave % (XD % NW);   // same parity as `wave`: a harmless repeat
+      if (kHand) glds16_m0(px + static_cast<size_t>(8 * j) * ldx, ox, stage + j * 1024);
+      else glds16_asm_s(px + static_cast<size_t>(8 * j) * ldx, ox, stage + j * 1024);
     } else {
-      const int j = wave + 8 * (p - XPW);
-      glds16_asm_s(pw + static_cast<size_t>(8 * j) * K, ow, stage + X_BYTES + j * 1024);
+      const int j = wave + NW * (p - XPW);
+      if (kHand) glds16_m0(pw + static_cast<size_t>(8 * j) * K, ow, stage + X_BYTES + j * 1024);
+      else glds16_asm_s(pw + static_cast<size_t>(8 * j) * K, ow, stage + X_BYTES + j * 1024);
     }
   };
   // fragment addresses: row = base + 16 q + (lane & 15); the swizzle key (row >> 1) & 7 = (lane & 15) >> 1 because
@@ -72,6 +112,9 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_big(const T* __restrict__ X,
   const char* const fx_base = smem + wm * 96 * ROW_BYTES;
   const char* const fw_base = smem + X_BYTES + wn * 64 * ROW_BYTES;
 
+  if constexpr (kPrioYoung) {      // the later-dispatched half of an 8-wave workgroup loses issue arbitration on its SIMD
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  }
   const int nk = K / BK;                                             // even (checked by the launcher)
   int tile = lo + t;
   const T* sx = X + static_cast<size_t>((tile / n_tiles) * TM) * ldx;
@@ -101,10 +144,51 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_big(const T* __restrict__ X,
       const char* bw = fw_base + S * STAGE;
       const uint32_t nxt = lds_base + (S ^ 1) * STAGE;
       __builtin_amdgcn_sched_barrier(0);
-      if (first) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();        // every wave's pieces of this k-step have landed; stage S ^ 1 is no longer read
+      if constexpr (!kNoSync) {
+        if (first) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // every wave's pieces of this k-step have landed; stage S ^ 1 is no longer read
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ABL == 2) {
+#pragma unroll
+        for (int g = 0; g < NDMA; ++g) dma(g, px, pw, nxt);
+      } else if constexpr (kHand) {
+        // issue order of the 20 fragment reads of a k-step: W0..3 X0 X1 | g0: X2 | g1: X3 | g2: X4 W'0 | g3: X5 W'1 | g4: X6 W'2 |
+        // g5: X7 W'3 | g6: X8 | g7: X9 | g8: X10 | g9: X11 (X six row blocks per k-half, W' = the second k-half's W fragments);
+        // group g consumes X_g (and W at g = 0, W' at g = 6): the counts below are the reads younger than what it needs
+        const uint32_t ax0 = lds_base + S * STAGE + wm * 96 * ROW_BYTES + fo0, ax1 = ax0 - fo0 + fo1;
+        const uint32_t aw0 = lds_base + S * STAGE + X_BYTES + wn * 64 * ROW_BYTES + fo0, aw1 = aw0 - fo0 + fo1;
+        uintx4 fw0[4], fw1[4], fx[3];
+        if constexpr (kNoReads) {
+          const uintx4 junk = {0x3f803f80u + lane * 0x10001u, 0x3f003e80u ^ (lane << 7), 0xbf80bf00u + S, 0x3e803f00u ^ lane};
+          for (int q = 0; q < 4; ++q) { fw0[q] = junk + q; fw1[q] = junk * (q + 3); }
+          fx[0] = junk + 7; fx[1] = junk * 5; fx[2] = junk + 11;
+          for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(fw0[q]), "+v"(fw1[q]));
+          asm volatile("" : "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]));
+        } else {
+          static_for<4>([&](auto NT) { lds_read16(fw0[NT.value], aw0, NT.value * 16 * ROW_BYTES); });
+          lds_read16(fx[0], ax0, 0);
+          lds_read16(fx[1], ax0, 16 * ROW_BYTES);
+        }
+        static_for<12>([&](auto G) {
+          constexpr int g = G.value, ks = g / 6, mt = g % 6;
+          if constexpr (!kNoReads) {
+            if constexpr (g + 2 < 12) lds_read16(fx[(g + 2) % 3], (g + 2) / 6 ? ax1 : ax0, ((g + 2) % 6) * 16 * ROW_BYTES);
+            if constexpr (ks == 0 && mt >= 2) lds_read16(fw1[mt - 2], aw1, (mt - 2) * 16 * ROW_BYTES);
+          }
+          if constexpr (g < NDMA && ABL != 1) dma(g, px, pw, nxt);
+          constexpr int kWait[12] = {2, 2, 3, 4, 5, 5, 1, 2, 2, 2, 1, 0};
+          if constexpr (kNoReads) {}
+          else if constexpr (g == 0) lds_wait<kWait[g]>(fw0[0], fw0[1], fw0[2], fw0[3], fx[0]);
+          else if constexpr (g == 6) lds_wait<kWait[g]>(fw1[0], fw1[1], fw1[2], fw1[3], fx[g % 3]);
+          else lds_wait<kWait[g]>(fx[g % 3]);
+          if constexpr (kPrioMfma) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mma<T>(__builtin_bit_cast(uint4, ks ? fw1[nt] : fw0[nt]), __builtin_bit_cast(uint4, fx[g % 3]), acc[nt][mt]);
+          if constexpr (kPrioMfma) __builtin_amdgcn_s_setprio(0);
+        });
+      } else {
       uint4 fw[2][4], fx[3];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) fw[0][nt] = *reinterpret_cast<const uint4*>(bw + nt * 16 * ROW_BYTES + fo0);
@@ -118,9 +202,10 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_big(const T* __restrict__ X,
           fx[g2 % 3] = *reinterpret_cast<const uint4*>(bx + (g2 % 6) * 16 * ROW_BYTES + (g2 / 6 ? fo1 : fo0));
         }
         if (ks == 0 && mt >= 2) fw[1][mt - 2] = *reinterpret_cast<const uint4*>(bw + (mt - 2) * 16 * ROW_BYTES + fo1);
-        if (g < NDMA) dma(g, px, pw, nxt);
+        if (g < NDMA && ABL != 1) dma(g, px, pw, nxt);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mma<T>(fw[ks][nt], fx[g % 3], acc[nt][mt]);
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -141,16 +226,29 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_big(const T* __restrict__ X,
     sw = sw_next;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the unused look-ahead pieces must not outlive the workgroup's LDS
+  if constexpr (kStamp) {
+    if (blockIdx.x == 0 && tid == 0) {
+      g_big_stamp[0] = __builtin_amdgcn_s_memtime() - stamp_c;
+      g_big_stamp[1] = __builtin_amdgcn_s_memrealtime() - stamp_r;
+    }
+  }
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
 }  // namespace
 
-// 0 = not applicable; 1 = 96 x 512 tiles, 2 = 192 x 256 tiles.  `want` (tuning knob): 0 auto, 1 / 2 forced.
+// Tile geometries: id 1 = 96 x 512 (1 x 8 waves), 2 = 192 x 256 (2 x 4 waves), 3 = 192 x 128 (2 x 2 waves, two workgroups per CU)
+static void big_geometry(int id, int& tm, int& tn, int& waves) {
+  tm = id == 1 ? 96 : 192;
+  tn = id == 1 ? 512 : id == 2 ? 256 : 128;
+  waves = id == 3 ? 4 : 8;
+}
+
+// 0 = not applicable, else the geometry id.  `want` (tuning knob): 0 auto, 1 / 2 / 3 forced.
 int big_linear_tile(int dtype, const LinearArgs& a, int want) {
   if (dtype != D3PM_F16 && dtype != D3PM_BF16) return 0;
-  if (a.K < 4 * BK || a.K % (2 * BK) != 0 || a.M < 96 || a.N < 256) return 0;
+  if (a.K < 4 * BK || a.K % (2 * BK) != 0 || a.M < 96 || a.N < 128) return 0;
   if (a.ldx % 8 != 0 || a.ldy % 8 != 0 || !aligned16(a.X) || !aligned16(a.W) || !aligned16(a.Y)) return 0;
   if (a.R1 && (a.ldr % 8 != 0 || !aligned16(a.R1))) return 0;
   if (a.R2 && (!a.R1 || !aligned16(a.R2))) return 0;
@@ -159,61 +257,100 @@ int big_linear_tile(int dtype, const LinearArgs& a, int want) {
   if (gelu && (r1 || mk)) return 0;                       // instantiated epilogues: plain, GELU, R1, R1+R2, R1+mask
   if (mk && (!r1 || r2)) return 0;
   if (a.ldx >= (1 << 24) || a.K >= (1 << 24)) return 0;       // 32-bit per-lane DMA offsets
-  auto fits = [&](int wm, bool forced) {
-    const int tm = 96 * wm, tn = 64 * (8 / wm);
+  auto fits = [&](int id, bool forced) {
+    int tm, tn, waves;
+    big_geometry(id, tm, tn, waves);
     if (a.M % tm != 0 || a.N % tn != 0) return false;
     if (forced) return true;                                        // tuning knob / kernel tests: any shape of whole tiles
-    const long long tiles = static_cast<long long>(a.M / tm) * (a.N / tn), rounds = (tiles + 255) / 256;
-    return tiles >= 200 && tiles * 100 >= rounds * 256 * 85;        // >= 85 % of the CU-rounds do work
+    const long long slots = 256 * (8 / waves);
+    const long long tiles = static_cast<long long>(a.M / tm) * (a.N / tn), rounds = (tiles + slots - 1) / slots;
+    return tiles * 5 >= slots * 4 && tiles * 100 >= rounds * slots * 85;   // >= 85 % of the slot-rounds do work
   };
-  if (want == 1 || want == 2) return fits(want, true) ? want : 0;
+  if (want >= 1 && want <= 3) return fits(want, true) ? want : 0;
+  // measured at the bench shapes (tests/ab_gemm.py, profiles/round2_*): 192 x 256 wins everywhere except under the GELU
+  // epilogue, whose VALU work only overlaps with MFMAs when a second workgroup shares the CU (192 x 128, two per CU)
+  if (gelu && fits(3, false)) return 3;
   if (fits(2, false)) return 2;
+  if (fits(3, false)) return 3;
   return fits(1, false) ? 1 : 0;
 }
 
-int big_linear(int dtype, const LinearArgs& a, int wm, hipStream_t s) {
-  const int tm = 96 * wm, tn = 64 * (8 / wm);
+static int g_big_mode = 1;      // kernel MODE template argument (tuning / ablation builds); 1 = shipped schedule (hand-placed reads)
+void set_big_gemm_mode(int v) { g_big_mode = v; }
+int read_big_gemm_stamp(unsigned long long* out) {
+  D3PM_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_stamp), 2 * sizeof(unsigned long long)));
+  return D3PM_OK;
+}
+
+template <typename U, int E, int WM, int WN, int MD>
+static int big_launch(const LinearArgs& a, int n_tiles, int tiles_total, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_big<U, E, WM, WN, MD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  gemm_mfma_big<U, E, WM, WN, MD><<<grid, dim3(WM * WN * 64), lds, s>>>(
+      static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
+      static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles,
+      tiles_total);
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+template <typename U, int E>
+static int big_launch_geometry(int id, const LinearArgs& a, int n_tiles, int tiles_total, dim3 grid, size_t lds, hipStream_t s) {
+  const int md = g_big_mode;
+  if (E == 0 && id == 3 && md >= 16) {
+    switch (md) {
+      case 17: return big_launch<U, 0, 2, 2, 17>(a, n_tiles, tiles_total, grid, lds, s);
+      case 209: return big_launch<U, 0, 2, 2, 209>(a, n_tiles, tiles_total, grid, lds, s);
+      default: break;
+    }
+  }
+  if (E == 0 && id == 2 && (md == 3 || md == 5)) {
+    if (md == 3) return big_launch<U, 0, 2, 4, 3>(a, n_tiles, tiles_total, grid, lds, s);
+    return big_launch<U, 0, 2, 4, 5>(a, n_tiles, tiles_total, grid, lds, s);
+  }
+  if (E == 0 && id == 2 && md >= 16) {      // timing-only ablation builds (tests/ab_gemm.py): plain epilogue, 192 x 256 only
+    switch (md) {
+      case 17: return big_launch<U, 0, 2, 4, 17>(a, n_tiles, tiles_total, grid, lds, s);
+      case 32: return big_launch<U, 0, 2, 4, 32>(a, n_tiles, tiles_total, grid, lds, s);
+      case 81: return big_launch<U, 0, 2, 4, 81>(a, n_tiles, tiles_total, grid, lds, s);
+      case 145: return big_launch<U, 0, 2, 4, 145>(a, n_tiles, tiles_total, grid, lds, s);
+      case 209: return big_launch<U, 0, 2, 4, 209>(a, n_tiles, tiles_total, grid, lds, s);
+      case 257: return big_launch<U, 0, 2, 4, 257>(a, n_tiles, tiles_total, grid, lds, s);
+      case 465: return big_launch<U, 0, 2, 4, 465>(a, n_tiles, tiles_total, grid, lds, s);
+      default: break;
+    }
+  }
+  const bool hand = (md & 1) != 0;
+  if (id == 1) return hand ? big_launch<U, E, 1, 8, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 1, 8, 0>(a, n_tiles, tiles_total, grid, lds, s);
+  if (id == 2) return hand ? big_launch<U, E, 2, 4, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 2, 4, 0>(a, n_tiles, tiles_total, grid, lds, s);
+  return hand ? big_launch<U, E, 2, 2, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 2, 2, 0>(a, n_tiles, tiles_total, grid, lds, s);
+}
+
+int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s) {
+  int tm, tn, waves;
+  big_geometry(id, tm, tn, waves);
   const int n_tiles = a.N / tn, tiles_total = (a.M / tm) * n_tiles;
-  const int want = (tiles_total + 7) & ~7;
-  const dim3 grid(static_cast<unsigned>(want < 256 ? want : 256)), block(512);
+  const int slots = 256 * (8 / waves), want = (tiles_total + 7) & ~7;
+  const dim3 grid(static_cast<unsigned>(want < slots ? want : slots));
   const size_t lds = 2 * static_cast<size_t>(tm + tn) * ROW_BYTES;
   const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
-#define D3PM_BIG(E, WMV)                                                                                              \
-  do {                                                                                                                \
-    static bool attr_set = false;                                                                                     \
-    if (!attr_set) {                                                                                                  \
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_big<U, E, WMV>),                    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
-    gemm_mfma_big<U, E, WMV><<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),  \
-        static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy, static_cast<const U*>(a.R1),                     \
-        static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles, tiles_total);         \
-    return D3PM_OK;                                                                                                   \
-  } while (0)
-#define D3PM_BIG_WM(E)         \
-  do {                         \
-    if (wm == 2) D3PM_BIG(E, 2); \
-    else D3PM_BIG(E, 1);       \
-  } while (0)
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
     switch (epi) {
-      case 0: D3PM_BIG_WM(0);
-      case EPI_GELU: D3PM_BIG_WM(EPI_GELU);
-      case EPI_R1: D3PM_BIG_WM(EPI_R1);
-      case EPI_R2: D3PM_BIG_WM(EPI_R2);
-      case EPI_R1 | EPI_MASK: D3PM_BIG_WM(EPI_R1 | EPI_MASK);
+      case 0: return big_launch_geometry<U, 0>(id, a, n_tiles, tiles_total, grid, lds, s);
+      case EPI_GELU: return big_launch_geometry<U, EPI_GELU>(id, a, n_tiles, tiles_total, grid, lds, s);
+      case EPI_R1: return big_launch_geometry<U, EPI_R1>(id, a, n_tiles, tiles_total, grid, lds, s);
+      case EPI_R2: return big_launch_geometry<U, EPI_R2>(id, a, n_tiles, tiles_total, grid, lds, s);
+      case EPI_R1 | EPI_MASK: return big_launch_geometry<U, EPI_R1 | EPI_MASK>(id, a, n_tiles, tiles_total, grid, lds, s);
       default: break;
     }
     return D3PM_E_SHAPE;
   };
-  int rc = dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
-#undef D3PM_BIG_WM
-#undef D3PM_BIG
-  if (rc != D3PM_OK) return rc;
-  D3PM_LAUNCH_CHECK();
-  return D3PM_OK;
+  return dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
 }
 
 }  // namespace d3pm

@@ -15,7 +15,7 @@ import torch
 F32, F16, BF16 = 0, 1, 2
 ABI_VERSION = 2
 FLAG_GREEDY, FLAG_FORCE_GENERIC, FLAG_SEED_IN_HBM = 1, 2, 4
-K_GEMM, K_ATTN, K_SAMPLE, K_LN = 0, 1, 2, 3
+K_GEMM, K_ATTN, K_SAMPLE, K_LN, K_ALL = 0, 1, 2, 3, 4
 
 _DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 LIB_PATH = os.environ.get("D3PM_HIP_LIB") or os.path.normpath(
@@ -135,9 +135,12 @@ SIGNATURES = {
     "d3pm_op_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_float, C.c_void_p]),
     "d3pm_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "d3pm_debug_gemm_clock": (C.c_int, [C.POINTER(C.c_uint64)]),
     "d3pm_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "d3pm_prof_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double)]),
+    "d3pm_prof_read_class": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double)]),
     "d3pm_prof_disable": (C.c_int, []),
 }
 
@@ -283,11 +286,28 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _require(t, name, shape, dtypes, device):
+    """The C ABI takes raw pointers and derives every extent from the shape struct: a tensor of another shape, dtype,
+    layout or device would be read / written out of bounds without any error, so it is rejected here."""
+    if not isinstance(t, torch.Tensor):
+        raise D3PMError(f"{name}: expected a tensor, got {type(t).__name__}")
+    if tuple(t.shape) != tuple(shape):
+        raise D3PMError(f"{name}: shape {tuple(t.shape)} != expected {tuple(shape)}")
+    if t.dtype not in dtypes:
+        raise D3PMError(f"{name}: dtype {t.dtype} not in {tuple(dtypes)}")
+    if t.device != device:
+        raise D3PMError(f"{name}: on {t.device}, the sampler lives on {device}")
+    if not t.is_contiguous():
+        raise D3PMError(f"{name}: must be contiguous")
+
+
 class Sampler:
     """Thin object API over the C entry points for one (shape, weights) pair."""
 
     def __init__(self, cfg, tensors: dict, dtype: torch.dtype, device, pe_text0=None, pe_prompt=None):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.shape = make_shape(cfg, dtype)
         self.weights = DeviceWeights(tensors, cfg.n_layers)
         self._tensors, self._fp8 = tensors, None
@@ -348,9 +368,27 @@ class Sampler:
                                  _p(cond_prompt), _p(kv_t), _p(kv_p), stream_ptr()), "d3pm_cond_kv")
         return kv_t, kv_p
 
+    def _check_grid(self, x, frame_mask=None, name="x_t"):
+        cfg = self.cfg
+        if not isinstance(x, torch.Tensor) or x.dim() != 2:
+            raise D3PMError(f"{name}: expected an int32 [B, {cfg.canvas}] token grid")
+        _require(x, name, (x.shape[0], cfg.canvas), (torch.int32,), self.device)
+        if x.shape[0] < 1:
+            raise D3PMError(f"{name}: empty batch")
+        if frame_mask is not None:
+            _require(frame_mask, "frame_mask", (cfg.canvas,), (torch.uint8,), self.device)
+        return x.shape[0]
+
+    def _check_kv(self, kv_t, kv_p, B):
+        cfg = self.cfg
+        _require(kv_t, "kv_text", (cfg.n_layers, B, cfg.s_text, 2 * cfg.d_model), (self.dtype,), self.device)
+        _require(kv_p, "kv_prompt", (cfg.n_layers, B, cfg.s_prompt, 2 * cfg.d_model), (self.dtype,), self.device)
+
     def denoise(self, x_t, frame_mask, t, kv_t, kv_p, *, want_logits=True, want_hidden=False, only_layers=-1,
                 flags=0, fp8=False):
-        cfg, B = self.cfg, x_t.shape[0]
+        cfg = self.cfg
+        B = self._check_grid(x_t, frame_mask)
+        self._check_kv(kv_t, kv_p, B)
         ws = self.workspace(B)
         logits = torch.empty((B, cfg.canvas, cfg.n_classes), dtype=self.dtype, device=self.device) if want_logits else None
         hidden = torch.empty((B, cfg.canvas, cfg.d_model), dtype=self.dtype, device=self.device) if want_hidden else None
@@ -366,8 +404,10 @@ class Sampler:
         return logits, hidden
 
     def posterior_sample(self, logits, x_t, t, seed, utt0=0, flags=0, want_posterior=False):
-        cfg, B = self.cfg, x_t.shape[0]
-        logits = logits.contiguous()
+        cfg = self.cfg
+        B = self._check_grid(x_t)
+        logits = logits.contiguous() if isinstance(logits, torch.Tensor) else logits
+        _require(logits, "logits", (B, cfg.canvas, cfg.n_classes), tuple(_DTYPES), self.device)
         x_next = torch.empty_like(x_t)
         post = torch.empty((B, cfg.canvas, cfg.n_classes), dtype=torch.int16, device=self.device) if want_posterior else None
         check(lib().d3pm_posterior_sample(C.byref(self.shape), B, _p(logits), dtype_code(logits.dtype), _p(x_t),
@@ -377,7 +417,9 @@ class Sampler:
 
     def sample_loop(self, x, frame_mask, t_start, t_stop, kv_t, kv_p, seed, utt0=0, flags=0, trace=False, slot=0,
                     fp8=False):
-        cfg, B = self.cfg, x.shape[0]
+        cfg = self.cfg
+        B = self._check_grid(x, frame_mask, "x")
+        self._check_kv(kv_t, kv_p, B)
         ws = self.workspace(B, slot)
         tr = torch.empty((t_start - t_stop, B, cfg.canvas), dtype=torch.int32, device=self.device) if trace else None
         if fp8:
@@ -395,8 +437,9 @@ class Sampler:
 
     def ce_loss_rows(self, logits, targets, frame_mask):
         """fp32 [B, canvas] cross-entropy rows of masked logits against masked targets (d3pm_ce_loss_rows)."""
-        B = logits.shape[0]
-        logits = logits.contiguous()
+        B = self._check_grid(targets, frame_mask, "targets")
+        logits = logits.contiguous() if isinstance(logits, torch.Tensor) else logits
+        _require(logits, "logits", (B, self.cfg.canvas, self.cfg.n_classes), tuple(_DTYPES), self.device)
         out = torch.empty((B, self.cfg.canvas), dtype=torch.float32, device=self.device)
         check(lib().d3pm_ce_loss_rows(C.byref(self.shape), B, _p(logits), dtype_code(logits.dtype), _p(targets),
                                       _p(frame_mask), _p(out), stream_ptr()), "d3pm_ce_loss_rows")
@@ -455,6 +498,7 @@ class Sampler:
         x.copy_(st["x"])
 
     def q_sample(self, x0, frame_mask, t, seed, utt0=0):
+        self._check_grid(x0, frame_mask, "x0")
         out = torch.empty_like(x0)
         check(lib().d3pm_q_sample(C.byref(self.shape), x0.shape[0], _p(x0), _p(out), _p(frame_mask), int(t),
                                   C.byref(self.schedule.c_struct), seed, utt0, stream_ptr()), "d3pm_q_sample")
@@ -584,6 +628,18 @@ def set_attn_pair_sequential(v: bool):
     check(lib().d3pm_set_tuning(3, 1 if v else 0), "d3pm_set_tuning")
 
 
+def set_gemm_big_mode(v: int):
+    check(lib().d3pm_set_tuning(4, v), "d3pm_set_tuning")
+
+
+def gemm_clock_ghz() -> float:
+    """Shader clock (GHz) held during the last big-tile GEMM launched with big mode bit 8 set; synchronises."""
+    torch.cuda.synchronize()
+    buf = (C.c_uint64 * 2)()
+    check(lib().d3pm_debug_gemm_clock(buf), "d3pm_debug_gemm_clock")
+    return buf[0] / max(buf[1], 1) * 0.1
+
+
 def set_gemm_persist_slots(v: int):
     check(lib().d3pm_set_tuning(2, v), "d3pm_set_tuning")
 
@@ -600,6 +656,13 @@ def prof_enable(kclass: int, max_events: int):
 def prof_read():
     n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
     check(lib().d3pm_prof_read(C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "d3pm_prof_read")
+    return n.value, ms.value, fl.value, by.value
+
+
+def prof_read_class(kclass: int):
+    """(launches, total ms, algorithmic flops, algorithmic bytes) of one kernel class; does not reset."""
+    n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+    check(lib().d3pm_prof_read_class(kclass, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "d3pm_prof_read_class")
     return n.value, ms.value, fl.value, by.value
 
 

@@ -103,19 +103,21 @@ class NAR(nn.Module):
         return self._runner
 
     def _pack(self, text_list, proms_list, resps_list):
-        dev, B = self.device, len(text_list)
-        lens = torch.tensor([[len(t), len(p), len(r)] for t, p, r in zip(text_list, proms_list, resps_list)], dtype=torch.int32)
-        tt, tp, tr = (int(v) for v in lens.max(0).values)
-        text = torch.zeros((B, tt), dtype=torch.int32)
-        prom = torch.full((B, tp, self.n_prom_levels), -1, dtype=torch.int32)
-        resp = torch.zeros((B, tr, self.n_resp_levels + 1), dtype=torch.int32)
-        for b, (t, p, r) in enumerate(zip(text_list, proms_list, resps_list)):
-            text[b, : len(t)] = t.to(torch.int32).cpu()
-            prom[b, : len(p), : p.shape[-1]] = p.to(torch.int32).cpu()
-            prom[b, len(p):] = 0
-            resp[b, : len(r), : r.shape[-1]] = r.to(torch.int32).cpu()
-        t_max = int((lens.sum(1) + 2).max())
-        return lens.to(dev), text.to(dev), prom.to(dev), resp.to(dev), t_max
+        """Ragged lists -> padded int32 grids on the model's device.  The lengths come from the tensors' shapes (host
+        integers): nothing here reads device memory back, so a batch that is already on the GPU (the D3PM stage's output)
+        is packed without a single synchronisation."""
+        import torch.nn.functional as F
+        from torch.nn.utils.rnn import pad_sequence
+        dev = self.device
+        lens_host = [(len(t), len(p), len(r)) for t, p, r in zip(text_list, proms_list, resps_list)]
+        i32 = lambda x: x.to(device=dev, dtype=torch.int32, non_blocking=True)
+        text = pad_sequence([i32(t) for t in text_list], batch_first=True)
+        # absent prompt levels are -1 (they contribute nothing), padded prompt rows are 0 like upstream's zero padding
+        prom = pad_sequence([F.pad(i32(p), (0, self.n_prom_levels - p.shape[-1]), value=-1) for p in proms_list], batch_first=True)
+        resp = pad_sequence([F.pad(i32(r), (0, self.n_resp_levels + 1 - r.shape[-1])) for r in resps_list], batch_first=True)
+        lens = torch.tensor(lens_host, dtype=torch.int32).to(dev, non_blocking=True)
+        t_max = max(a + b_ + c for a, b_, c in lens_host) + 2
+        return lens, text.contiguous(), prom.contiguous(), resp.contiguous(), t_max, lens_host
 
     @torch.no_grad()
     def forward(self, text_list: Sequence[Tensor], proms_list: Sequence[Tensor], resps_list: Sequence[Tensor],
@@ -130,7 +132,7 @@ class NAR(nn.Module):
             raise NotImplementedError("the training branch of NAR.forward (nar.py:53-74) is outside this build's scope")
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        lens, text, prom, resp, t_max = self._pack(text_list, proms_list, resps_list)
+        lens, text, prom, resp, t_max, lens_host = self._pack(text_list, proms_list, resps_list)
         run = self.runner(t_max)
         flags = _hip.FLAG_GREEDY if greedy else 0
         logits = None
@@ -140,5 +142,5 @@ class NAR(nn.Module):
                                want_logits=(return_logits_level == level))
                 if lg is not None:
                     logits = lg
-        out = [resp[b, : int(lens[b, 2])].long() for b in range(len(text_list))]
+        out = [resp[b, : lens_host[b][2]].long() for b in range(len(text_list))]
         return (out, logits, lens, t_max) if return_logits_level is not None else out
