@@ -445,6 +445,43 @@ def gen_nar(out):
     print("  nar: oracle == reference (logits levels 0/3, 7-level generation under torch seed 0)")
 
 
+def gen_formats(out):
+    """On-disk formats.  A three-utterance, two-speaker corpus is written the way the reference's
+    front-ends write it -- `.qnt.pt` = torch.save(int64 [1, 8, t]) (emb/qnt.py:93), `.phn.txt` = " ".join(phones)
+    (emb/g2p.py:47-48) -- and read back with the reference's OWN loaders (data.py:31-45 `_load_quants`, `_get_phones`;
+    data.py:119-134 phone / speaker symmaps of VALLEDatset).  The files and what the reference made of them are committed;
+    tests/test_formats.py requires formats.py to make the same of the same files."""
+    import json
+    import shutil
+    from pathlib import Path
+    data = rh.load_reference_data_module()
+    root = Path(out) / "formats"
+    if root.exists():
+        shutil.rmtree(root)
+    rng = np.random.default_rng(11)
+    phones_by_utt = {"spk_a/utt1": "HH AH0 L OW1 _ W ER1 L D _ AH0 G EH1 N", "spk_a/utt2": "DH AH0 _ K W IH1 K _ B R AW1 N _ F AA1 K S",
+                     "spk_b/utt3": "S P IY1 CH _ S IH1 N TH AH0 S AH0 S _ T EH1 S T"}
+    paths = []
+    for rel, phones in phones_by_utt.items():
+        p = root / (rel + ".wav")                    # the loaders derive .qnt.pt / .phn.txt from the audio path
+        p.parent.mkdir(parents=True, exist_ok=True)
+        qnt = torch.from_numpy(rng.integers(0, 1024, size=(1, 8, int(rng.integers(12, 30))))).long()
+        torch.save(qnt.cpu(), data._replace_file_extension(p, ".qnt.pt"))           # emb/qnt.py:93
+        with open(data._replace_file_extension(p, ".phn.txt"), "w") as f:           # emb/g2p.py:47-48
+            f.write(phones)
+        paths.append(p)
+    ds = data.VALLEDatset(paths)
+    expect = {"phone_symmap": ds.phone_symmap, "spkr_symmap": ds.spkr_symmap, "utterances": {}}
+    for rel, p in zip(phones_by_utt, paths):
+        q = data._load_quants(p)
+        assert q.dtype == torch.int64 and q.shape[1] == 8
+        text = [*map(ds.phone_symmap.get, data._get_phones(p))]                     # data.py:166
+        expect["utterances"][rel] = {"quants_t_q": q.tolist(), "phones": data._get_phones(p), "text_ids": text}
+    with open(root / "expected.json", "w") as f:
+        json.dump(expect, f, indent=1, sort_keys=True)
+    print(f"  formats: {len(paths)} utterances, {len(ds.phone_symmap)} phones, speakers {ds.spkr_symmap}")
+
+
 def main():
     assert rh.reference_available(), "needs /root/reference (build container only)"
     torch.manual_seed(0)
@@ -455,6 +492,7 @@ def main():
     print("forward ..."); gen_forward(out, m)
     print("wide ...");   gen_wide(out, m)
     print("nar ...");    gen_nar(out)
+    print("formats ..."); gen_formats(out)
     with open(os.path.join(out, "FINGERPRINT.txt"), "w") as f:
         f.write(fingerprint() + "\n")
     print("done:", fingerprint())

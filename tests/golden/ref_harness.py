@@ -129,3 +129,33 @@ def build_reference_native():
     with cuda_strings_as_cpu():
         model = ard.AR(512, 100, 1024, 8, 8, 6)
     return model.eval()
+
+
+def load_reference_data_module():
+    """/root/reference/vall_e/data.py executed from source (its `_load_quants`, `_get_phones`, `VALLEDatset` symmaps are the
+    reference's statement of the on-disk formats).  Its package imports need omegaconf / diskcache (`.config`), absent
+    here: `.config` is replaced by a stub carrying the three fields data.py reads, with the reference's own defaults
+    (config.py:41-44); `.sampler` is the reference's file."""
+    name = _PKG + "_top"
+    if name + ".data" in sys.modules:
+        return sys.modules[name + ".data"]
+    top_dir = os.path.join(REF_ROOT, "vall_e")
+    pkg = types.ModuleType(name)
+    pkg.__path__ = [top_dir]
+    sys.modules[name] = pkg
+    cfg_mod = types.ModuleType(name + ".config")
+
+    class _Cfg:
+        min_phones, max_phones = 10, 50                  # config.py:43-44
+        max_prompts, p_additional_prompt = 3, 0.8
+        diskcache = staticmethod(lambda: lambda fn: fn)  # config.py:90-93 with cache_dataloader off: the identity decorator
+        get_spkr = staticmethod(lambda p: p.parts[-2])   # config.py:41 is `p.parts[-1]` (the file name itself); the LibriTTS /
+                                                         # VCTK yml files of the reference override it with parts[-2]
+    cfg_mod.cfg = _Cfg()
+    sys.modules[name + ".config"] = cfg_mod
+    for mod_name in ("sampler", "data"):
+        spec = importlib.util.spec_from_file_location(f"{name}.{mod_name}", os.path.join(top_dir, mod_name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"{name}.{mod_name}"] = mod
+        spec.loader.exec_module(mod)
+    return sys.modules[name + ".data"]

@@ -88,7 +88,46 @@ def _sinusoid_table(n: int, d_model: int, dtype: torch.dtype) -> Tensor:
     return torch.cat([ang.sin(), ang.cos()], dim=-1)
 
 
-class AR(nn.Module):
+class SymmapState:
+    """`phone_symmap` / `spkr_symmap` as the reference's export attaches them to the trained module
+    (/root/reference/vall_e/export.py:18-19; read back as `ar.phone_symmap` at /root/reference/vall_e/__main__.py:56).
+    Upstream ships them inside a whole-module pickle; here they ride in the state dict under one extra key,
+    `_symmaps`, present only when a map is set -- so a state dict exported upstream (no such key) loads strictly,
+    and a state dict saved here loads upstream after `sd.pop("_symmaps", None)`."""
+    SYMMAP_KEY = "_symmaps"
+
+    def _init_symmaps(self):
+        self.phone_symmap: dict = {}      # {phone symbol: id >= 1}, data.py:125-127
+        self.spkr_symmap: dict = {}       # {speaker name: id >= 0}, data.py:133-134
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        if self.phone_symmap or self.spkr_symmap:
+            sd[prefix + self.SYMMAP_KEY] = {"phone_symmap": dict(self.phone_symmap), "spkr_symmap": dict(self.spkr_symmap)}
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        state_dict = dict(state_dict)
+        maps = state_dict.pop(self.SYMMAP_KEY, None)
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        if maps is not None:
+            self.phone_symmap = dict(maps.get("phone_symmap", {}))
+            self.spkr_symmap = dict(maps.get("spkr_symmap", {}))
+        return out
+
+    @classmethod
+    def load_exported(cls, path, **ctor):
+        """A checkpoint written by tools/convert_upstream_pickle.py (run once in the upstream environment on the
+        whole-module pickle of /root/reference/vall_e/export.py:20): {"state_dict", "phone_symmap", "spkr_symmap"}."""
+        blob = torch.load(path, map_location="cpu")
+        model = cls(**ctor) if ctor else cls.reference_native() if hasattr(cls, "reference_native") else cls()
+        model.load_state_dict(blob["state_dict"])
+        model.phone_symmap = dict(blob.get("phone_symmap") or {})
+        model.spkr_symmap = dict(blob.get("spkr_symmap") or {})
+        return model
+
+
+class AR(SymmapState, nn.Module):
     n_resp_levels = 1
     num_classes = N_CLASSES
 
@@ -122,6 +161,7 @@ class AR(nn.Module):
         self._sampler_key = None
         self.loop_streams = 1     # >1: the batch is cut into that many independent chunks on separate HIP streams
         self._streams = []
+        self._init_symmaps()
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod

@@ -17,6 +17,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _hip
+from .ar_discrete import SymmapState
 from .synth import NARConfig
 
 
@@ -64,7 +65,7 @@ class _BlockParams(nn.Module):
         self.ffn = _Prenorm(nn.Sequential(nn.Linear(d, 4 * d), nn.GELU(), nn.Dropout(0.0), nn.Linear(4 * d, d)), d, n_levels)
 
 
-class NAR(nn.Module):
+class NAR(SymmapState, nn.Module):
     n_resp_levels = 7
     n_prom_levels = 8
 
@@ -80,6 +81,7 @@ class NAR(nn.Module):
         self.classifier = nn.Linear(d_model, n_tokens)
         self._runner = None
         self._runner_key = None
+        self._init_symmaps()
 
     @property
     def dtype(self):
