@@ -683,7 +683,7 @@ int d3pm_set_tuning(int knob, int value) {
   if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || value == 2 || value == 3 || value == 5 || (value >= 6 && value <= 8))) { set_gemm_variant(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && value >= 0 && value <= 2) { set_attn_qg(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && (value == 0 || value == 1)) { set_attn_pair_sequential(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465)) { set_big_gemm_mode(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 9 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465)) { set_big_gemm_mode(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_PERSIST_SLOTS && value >= 8 && value <= 4096 && value % 8 == 0) { set_gemm_persist_slots(value); return D3PM_OK; }
   set_error("d3pm_set_tuning: unknown knob %d / value %d", knob, value);
   return D3PM_E_ARG;

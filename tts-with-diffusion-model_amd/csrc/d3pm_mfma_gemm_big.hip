@@ -53,7 +53,10 @@ __device__ __forceinline__ void glds16_m0(const void* sbase, uint32_t voff, uint
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-// MODE: bit 0 = hand-scheduled fragment reads (asm, counted lgkmcnt); the other bits are timing-only ablations (WRONG
+// MODE: bit 0 = hand-scheduled fragment reads (asm, counted lgkmcnt); bit 3 (8) = deferred stores: a tile's 12 output stores
+// per wave are issued a few per k-step inside the NEXT tile's main loop (all CUs finish their tiles together, so stores
+// issued in the epilogue arrive as one chip-wide burst that the HBM write path drains at ~5.5 TB/s while every MFMA pipe
+// idles: 4.5 us per 25 MB round; needs K >= 512); the other bits are timing-only ablations (WRONG
 // results): 16 = no DMA pieces in the k-loop, 32 = no fragment reads / MFMAs, 64 = no waits / barriers, 128 = the MFMAs
 // take their operands from registers (no LDS reads)
 __device__ unsigned long long g_big_stamp[4];   // MODE bit 8: {shader clocks, 100 MHz ticks} of block 0 (clock under load)
@@ -74,7 +77,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   constexpr bool kHand = (MODE & 1) != 0;
   constexpr int ABL = (MODE >> 4) & 3;
   constexpr bool kNoSync = (MODE & 64) != 0, kNoReads = (MODE & 128) != 0, kStamp = (MODE & 256) != 0;
-  constexpr bool kPrioYoung = (MODE & 2) != 0, kPrioMfma = (MODE & 4) != 0;
+  constexpr bool kPrioYoung = (MODE & 2) != 0, kPrioMfma = (MODE & 4) != 0, kDrip = (MODE & 8) != 0;
+  static_assert(!kDrip || kHand, "deferred stores ride in the hand-placed schedule");
+  constexpr int SPS = 12 - NDMA;                        // deferred stores per k-step: the MFMA groups behind the last DMA piece
+  constexpr int DRIP_STEPS = kDrip ? (12 + SPS - 1) / SPS : 0;          // 3 (192 x 256) or 6
+  constexpr int PEEL = kDrip ? ((DRIP_STEPS + 1 + 1) & ~1) : 2;           // k-steps written out per tile (even)
   unsigned long long stamp_c = 0, stamp_r = 0;
   if constexpr (kStamp) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,6 +131,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   // the first step of a tile waits with vmcnt(12): behind an epilogue the DMA pieces are older than its 12 stores; the very
   // first tile has no stores behind its pieces, so they are waited for here
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uintx4 pend[12];                // deferred-store mode: the previous tile, finished and packed
+#pragma unroll
+  for (int j = 0; j < 12; ++j) pend[j] = uintx4{0u, 0u, 0u, 0u};
+  T* pend_y = Y;
+  bool pending = false;
   for (;;) {
     floatx4 acc[4][6];
 #pragma unroll
@@ -138,15 +150,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
     const T* sx_next = X + static_cast<size_t>((tile_next / n_tiles) * TM) * ldx;
     const T* sw_next = W + static_cast<size_t>((tile_next % n_tiles) * TN) * K;
 
-    // one k-step on stage S while the DMA pieces of the following k-step (px, pw) go to stage S ^ 1
-    auto step = [&](const int S, const bool first, const T* px, const T* pw) __attribute__((always_inline)) {   // S, first: constants
+    // one k-step on stage S while the DMA pieces of the following k-step (px, pw) go to stage S ^ 1.  WAITN: what the wait at
+    // the top may leave in flight (the stores issued behind the previous k-step's last DMA piece); [ST0, ST0 + STN): the
+    // deferred stores of the previous tile that this k-step issues
+    auto step = [&](auto S_, auto WAITN_, auto ST0_, auto STN_, const T* px, const T* pw) __attribute__((always_inline)) {
+      constexpr int S = decltype(S_)::value, WAITN = decltype(WAITN_)::value, ST0 = decltype(ST0_)::value, STN = decltype(STN_)::value;
       const char* bx = fx_base + S * STAGE;
       const char* bw = fw_base + S * STAGE;
       const uint32_t nxt = lds_base + (S ^ 1) * STAGE;
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!kNoSync) {
-        if (first) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (WAITN > 0) {
+          if (!kDrip || pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();      // every wave's pieces of this k-step have landed; stage S ^ 1 is no longer read
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -187,6 +206,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mma<T>(__builtin_bit_cast(uint4, ks ? fw1[nt] : fw0[nt]), __builtin_bit_cast(uint4, fx[g % 3]), acc[nt][mt]);
           if constexpr (kPrioMfma) __builtin_amdgcn_s_setprio(0);
+          if constexpr (kDrip && g >= NDMA && g - NDMA < STN) {
+            constexpr int j = ST0 + g - NDMA;          // store j = (row block j / 2, column pair j % 2) of the previous tile
+            if (pending) *reinterpret_cast<uintx4*>(pend_y + static_cast<size_t>((j / 2) * 16) * ldy + (j % 2) * 32) = pend[j];
+          }
         });
       } else {
       uint4 fw[2][4], fx[3];
@@ -210,15 +233,35 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
       __builtin_amdgcn_sched_barrier(0);
     };
 
-    step(0, true, sx + BK, sw + BK);
-    step(1, false, sx + 2 * BK, sw + 2 * BK);
-    for (int kt = 2; kt < nk; kt += 2) {                 // nk is even and >= 4
-      step(0, false, sx + (kt + 1) * BK, sw + (kt + 1) * BK);
-      const bool last = kt + 2 >= nk;
-      step(1, false, last ? sx_next : sx + (kt + 2) * BK, last ? sw_next : sw + (kt + 2) * BK);
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if constexpr (kDrip) {
+      static_for<PEEL>([&](auto SI) {                     // the k-steps that carry the previous tile's stores, written out
+        constexpr int si = SI.value;
+        constexpr int cnt = 12 - si * SPS < 0 ? 0 : (12 - si * SPS < SPS ? 12 - si * SPS : SPS);
+        constexpr int prev = si == 0 ? 0 : (12 - (si - 1) * SPS < 0 ? 0 : (12 - (si - 1) * SPS < SPS ? 12 - (si - 1) * SPS : SPS));
+        const bool lastk = si + 1 >= nk;
+        step(std::integral_constant<int, si & 1>{}, std::integral_constant<int, prev>{}, std::integral_constant<int, si * SPS>{},
+             std::integral_constant<int, cnt>{}, lastk ? sx_next : sx + (si + 1) * BK, lastk ? sw_next : sw + (si + 1) * BK);
+      });
+    } else {
+      step(I0{}, std::integral_constant<int, 12>{}, I0{}, I0{}, sx + BK, sw + BK);   // behind an epilogue: its 12 stores may stay in flight
+      step(I1{}, I0{}, I0{}, I0{}, sx + 2 * BK, sw + 2 * BK);
     }
-    epilogue_store<T, EPI, 4, 6, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
-                                       n0 + wn * 64, lane);
+    for (int kt = PEEL; kt < nk; kt += 2) {               // nk is even and >= PEEL
+      step(I0{}, I0{}, I0{}, I0{}, sx + (kt + 1) * BK, sw + (kt + 1) * BK);
+      const bool last = kt + 2 >= nk;
+      step(I1{}, I0{}, I0{}, I0{}, last ? sx_next : sx + (kt + 2) * BK, last ? sw_next : sw + (kt + 2) * BK);
+    }
+    if (kDrip && more) {      // keep the finished tile in registers: its stores go out inside the next tile's first k-steps
+      epilogue_store<T, EPI, 4, 6, true, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
+                                               n0 + wn * 64, lane, pend);
+      pend_y = Y + static_cast<size_t>(m0 + wm * 96 + (lane & 15)) * ldy + n0 + wn * 64 + epilogue_nq(lane);
+      pending = true;
+    } else {
+      epilogue_store<T, EPI, 4, 6, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
+                                         n0 + wn * 64, lane);
+    }
     if (!more) break;
     t = t_next;
     tile = tile_next;
@@ -325,9 +368,11 @@ static int big_launch_geometry(int id, const LinearArgs& a, int n_tiles, int til
     }
   }
   const bool hand = (md & 1) != 0;
-  if (id == 1) return hand ? big_launch<U, E, 1, 8, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 1, 8, 0>(a, n_tiles, tiles_total, grid, lds, s);
-  if (id == 2) return hand ? big_launch<U, E, 2, 4, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 2, 4, 0>(a, n_tiles, tiles_total, grid, lds, s);
-  return hand ? big_launch<U, E, 2, 2, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 2, 2, 0>(a, n_tiles, tiles_total, grid, lds, s);
+  // deferred stores need a next tile to hide in (more tiles than persistent workgroups) and K >= 8 k-steps
+  const bool drip = md == 9 && a.K >= 8 * BK && tiles_total > static_cast<int>(grid.x);
+  if (id == 1) return drip ? big_launch<U, E, 1, 8, 9>(a, n_tiles, tiles_total, grid, lds, s) : hand ? big_launch<U, E, 1, 8, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 1, 8, 0>(a, n_tiles, tiles_total, grid, lds, s);
+  if (id == 2) return drip ? big_launch<U, E, 2, 4, 9>(a, n_tiles, tiles_total, grid, lds, s) : hand ? big_launch<U, E, 2, 4, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 2, 4, 0>(a, n_tiles, tiles_total, grid, lds, s);
+  return drip ? big_launch<U, E, 2, 2, 9>(a, n_tiles, tiles_total, grid, lds, s) : hand ? big_launch<U, E, 2, 2, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 2, 2, 0>(a, n_tiles, tiles_total, grid, lds, s);
 }
 
 int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s) {

@@ -78,10 +78,16 @@ __device__ __forceinline__ void swap_rows16(float& a, float& b) {
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
-template <typename T, int EPI, int NT = 4, int MT = 4, bool kInteriorOnly = false>
+// kPack (interior tiles only): the MT * NT / 2 finished 16-byte groups go to `packed[mt * (NT / 2) + np]` instead of memory;
+// the caller stores group (mt, np) later at Y + (mw0 + (lane & 15) + 16 mt) * ldy + nw0 + epilogue_nq(lane) + 32 np.
+__device__ __forceinline__ int epilogue_nq(int lane) { const int g = lane >> 4; return (g & 1) * 16 + (g >> 1) * 8; }
+
+template <typename T, int EPI, int NT = 4, int MT = 4, bool kInteriorOnly = false, bool kPack = false>
 __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* __restrict__ bias, T* Y, int ldy,
                                                const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                               int mask_period, int M, int N, int mw0, int nw0, int lane) {
+                                               int mask_period, int M, int N, int mw0, int nw0, int lane,
+                                               uintx4* packed = nullptr) {
+  static_assert(!kPack || kInteriorOnly, "packing to registers is for whole tiles");
   static_assert(NT % 2 == 0, "column blocks are regrouped in pairs");
   constexpr bool kGelu = EPI & EPI_GELU, kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
   constexpr int NP = NT / 2;
@@ -162,8 +168,9 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
           }
           if (kMask) v[r] *= mk;
         }
-        *reinterpret_cast<uintx4*>(y + np * 32) =
-            uintx4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+        const uintx4 grp = uintx4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+        if constexpr (kPack) packed[mt * NP + np] = grp;
+        else *reinterpret_cast<uintx4*>(y + np * 32) = grp;
       }
       y += static_cast<size_t>(16) * ldy;
       if (kR1) r1 += static_cast<size_t>(16) * ldr;
