@@ -305,10 +305,12 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
 /* Tuning knobs (process-wide; defaults are what bench.py measures).
  * D3PM_TUNE_GEMM_VARIANT: 0 = auto (default): big-tile persistent schedule (192 x 256 or 96 x 512 tiles, eight waves,
  *                             one workgroup per CU) when the shape divides into >= 200 such tiles that fill whole rounds
- *                             of the 256 CUs, else latency schedule for M <= 1536 rows, 128 x 128 throughput schedule otherwise;
+ *                             of the 256 CUs, else latency schedule (64 x 64 tiles, whole-K operand panels in flight) for
+ *                             M <= 1536 rows, 128 x 128 throughput schedule otherwise;
  *                         2 = always the throughput schedule (one LDS stage, 4 workgroups per CU; persistent over the
  *                             128 x 128 tiles when M and N are multiples of 128 and there are >= 512 tiles, else as 5);
- *                         3 = always the latency schedule (two stages, asm DMA prefetch);
+ *                         3 = always the round-1 latency schedule (128 x 128 tiles, two stages, asm DMA prefetch);
+ *                         4 = always the latency schedule (64 x 64 tiles, every DMA piece of K <= 512 in flight at once);
  *                         5 = throughput schedule with one tile per workgroup (the non-persistent form of 2);
  *                         6 / 7 / 8 = as auto, but only the 192 x 256 / 96 x 512 / 192 x 128 (two 4-wave workgroups per CU) big
  *                             tile is considered, for any shape made of whole tiles.
@@ -319,13 +321,24 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *                         problems in every workgroup, one after the other; 0 = the second half of the grid takes problem 2.
  * D3PM_TUNE_GEMM_PERSIST_SLOTS: resident workgroups of the persistent throughput schedule, a multiple of 8
  *                         (default 1024 = 4 per CU).
+ * D3PM_TUNE_FUSED_FINAL_SAMPLE: 1 = inside d3pm_sample_loop the final projection, the posterior and the draw are one
+ *                         kernel and the logits never reach HBM (16-bit model, d_model a multiple of 32, MFMA family);
+ *                         0 (default: measured faster) = the two-launch form (final GEMM, then d3pm_posterior_sample's
+ *                         kernel).  Same ids either way.
  * D3PM_TUNE_GEMM_BIG_MODE: schedule of the big-tile GEMM: 1 (default) / 0 = hand-placed / compiler-placed fragment reads (same
  *                         results);
  *                         >= 16 = timing-only ablation builds for tests/ab_gemm.py (WRONG results; bits: 16 no DMA, 32 no
  *                         MFMA, 64 no barriers, 128 no LDS reads, 256 clock stamp for d3pm_debug_gemm_clock). */
 enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2,
-       D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4 };
+       D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4, D3PM_TUNE_FUSED_FINAL_SAMPLE = 5 };
 int d3pm_set_tuning(int knob, int value);
+
+/* Single-op entry of the fused final projection + posterior + draw (replaces `final` at ar_discrete.py:776 followed by
+ * p_sample :401-420): hidden [batch * canvas][d_model] (model dtype, already multiplied by the frame mask) -> x_next.
+ * Same arguments as d3pm_posterior_sample otherwise.  D3PM_E_SHAPE when the fused kernel does not apply. */
+int d3pm_op_final_sample(const d3pm_shape *shape, const d3pm_weights *w, int batch, const void *hidden, const int32_t *x_t,
+                         int32_t *x_next, int t, const d3pm_schedule *sched, uint64_t seed, uint32_t utt0, uint32_t flags,
+                         void *stream);
 /* Diagnostic: after a big-tile GEMM launched with D3PM_TUNE_GEMM_BIG_MODE bit 8 set (and a device synchronisation),
  * {shader clocks, 100 MHz reference ticks} that workgroup 0 spent in the kernel: clocks / ticks * 100 MHz = the clock the
  * chip held under that load (MI355X_MICROARCH.md "DVFS give-back" item 6).  No output of the kernel depends on it. */

@@ -70,7 +70,7 @@ def main():
             y = torch.empty(Ms, ldy, device=DEV, dtype=dtype)
             r = torch.randn(Ms, ldy, device=DEV).to(dtype) if res else None
             line = f"{name:10s} N={N:5d} K={K:5d}"
-            for variant in (2, 3):
+            for variant in (2, 3, 4):
                 _hip.set_gemm_variant(variant)
                 t = timeit(lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=ldy), 50)
                 line += f" | v{variant}: {t * 1e6:6.1f} us"

@@ -33,7 +33,7 @@ def gelu32(v):
     return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
 
 
-@pytest.fixture(params=[2, 3, 5, 6, 7, 8], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency", 5: "gemm_one_tile",
+@pytest.fixture(params=[2, 3, 4, 5, 6, 7, 8], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency_r1", 4: "gemm_latency", 5: "gemm_one_tile",
                                                           6: "gemm_big_192x256", 7: "gemm_big_96x512", 8: "gemm_big_192x128"}[v])
 def gemm_variant(request, built_lib):
     """Both schedules of the MFMA GEMM must pass the same numerics (auto selection is restored afterwards)."""
@@ -108,7 +108,7 @@ def test_gemm_schedules_are_bit_identical(built_lib):
     w = (torch.randn(1536, 512, generator=g) / math.sqrt(512)).to(torch.bfloat16).to(DEV)
     b = torch.randn(1536, generator=g).to(torch.bfloat16).to(DEV)
     outs = []
-    for v in (2, 3, 5):
+    for v in (2, 3, 4, 5):
         _hip.set_gemm_variant(v)
         outs.append(_hip.op_linear(x, w, b, act=1, family=_hip.FAMILY_MFMA).clone())
     _hip.set_gemm_variant(0)
@@ -165,7 +165,7 @@ def test_gemm_persistent_matches_one_tile_kernel(built_lib, dtype, epi):
     r2 = torch.randn(M, N, generator=g).to(dtype).to(DEV) if epi == "r1r2" else None
     mask = (torch.rand(T, generator=g) < 0.8).to(torch.uint8).to(DEV) if epi == "r1mask" else None
     outs = []
-    for v in (5, 2, 0, 3):
+    for v in (5, 2, 0, 3, 4):
         _hip.set_gemm_variant(v)
         outs.append(_hip.op_linear(x, w, b, act=1 if epi == "gelu" else 0, r1=r1, r2=r2, row_mask=mask, mask_period=T,
                                    family=_hip.FAMILY_MFMA).clone())
@@ -288,3 +288,47 @@ def test_linear_fp8_against_fp32_on_the_same_codes(built_lib, dtype, M, N, K, ac
     if act:
         ref = torch.nn.functional.gelu(ref.to(dtype).float())
     assert_close_lp(y, ref, dtype, f"fp8 linear {M}x{N}x{K} act{act}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_final_sample_equals_the_two_launch_path(built_lib, dtype):
+    """final projection + posterior + Gumbel-max draw in one kernel (d3pm_final_sample.hip; ar_discrete.py:773-779,401-420)
+    against the final GEMM followed by the stand-alone sampler: the logits are the same fp32 sums rounded the same way and
+    the draw is the same code over the same lane grouping, so the ids must be identical -- for masked and revealed tokens,
+    early and late steps, with and without noise."""
+    from vall_e.vall_e import AR, _hip, synth
+    cfg = synth.D3PMConfig.libritts()
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0, logit_gain=4.0))      # sharper logits: revealed tokens flip sometimes
+    m = m.to(dtype).to(DEV)
+    smp = m.sampler()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B = 3                                                                   # 2304 rows: 72 workgroups of 32 rows
+    hidden = torch.randn(B, cfg.canvas, cfg.d_model, generator=g).to(dtype).to(DEV)
+    x = torch.full((B, cfg.canvas), cfg.mask_id, dtype=torch.int32)
+    x[:, ::3] = torch.randint(0, 1024, x[:, ::3].shape, generator=g, dtype=torch.int32)
+    x[:, cfg.n_frames:] = 0
+    x = x.to(DEV)
+    for t, flags in ((99, 0), (50, 0), (1, 0), (40, _hip.FLAG_GREEDY)):
+        logits = _hip.op_linear(hidden.view(-1, cfg.d_model), m.final.weight, m.final.bias, family=_hip.FAMILY_MFMA, ldy=1032)
+        want, _ = smp.posterior_sample(logits.reshape(B, cfg.canvas, cfg.n_classes).contiguous(), x, t, seed=17, utt0=5, flags=flags)
+        got = smp.final_sample(hidden, x, t, seed=17, utt0=5, flags=flags)
+        assert torch.equal(got, want), f"t={t}: {(got != want).sum().item()} of {got.numel()} ids differ"
+    assert int(want.max()) <= 1024 and int(want.min()) >= 0
+
+
+def test_sample_loop_is_the_same_with_and_without_the_fused_final_kernel(built_lib):
+    from vall_e.vall_e import AR, _hip, synth
+    cfg = synth.D3PMConfig.libritts()
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0))
+    m = m.to(torch.bfloat16).to(DEV)
+    texts, proms = synth.make_inputs(cfg, 2, 1)
+    try:
+        _hip.set_fused_final_sample(False)
+        a = m.generate_audio(texts, proms, steps=6, seed=4)
+        _hip.set_fused_final_sample(True)
+        b = m.generate_audio(texts, proms, steps=6, seed=4)
+    finally:
+        _hip.set_fused_final_sample(False)
+    assert torch.equal(a, b)

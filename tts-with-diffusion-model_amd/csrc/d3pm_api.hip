@@ -30,6 +30,13 @@ void set_gemm_persist_slots(int v);
 void set_attn_pair_sequential(int v);
 void set_attn_qg(int v);
 void set_big_gemm_mode(int v);
+bool final_sample_supported(int dtype, int n_classes, int d, const void* X, int ldx, const void* W);
+int final_sample(int dtype, const void* X, int ldx, const void* W, const void* bias, int d, const SampleArgs& a, hipStream_t s);
+// D3PM_TUNE_FUSED_FINAL_SAMPLE.  Off by default: measured on MI355X (B = 32, bf16) the fused kernel takes 253 us per
+// iteration against 32 + 90 us for the two launches -- the draw is VALU-issue-bound (~1800 vector instructions per row and
+// lane: Philox, three logf, expf, a division, the fp16 rounding points) and wants 8 waves per SIMD, the fused kernel's 66 KB
+// logits image allows 2
+static int g_fused_final_sample = 0;
 int read_big_gemm_stamp(unsigned long long* out);
 
 // ---- profiling hooks (bench.py roofline object) ----------------------------------------------
@@ -261,6 +268,12 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
   return D3PM_OK;
 }
 
+// the fused final + sampler kernel takes over wherever the final projection would have run on the MFMA family
+static bool fused_final_sample_applies(const d3pm_shape& sh, const d3pm_weights& w, const Workspace& ws, uint32_t flags) {
+  return g_fused_final_sample && !(flags & D3PM_FLAG_FORCE_GENERIC) && sh.d_model >= 64 &&
+         final_sample_supported(sh.dtype, sh.n_classes, sh.d_model, ws.x, sh.d_model, w.final_w);
+}
+
 static int final_logits(const d3pm_shape& sh, const d3pm_weights& w, int batch, const Workspace& ws, void* logits,
                         int ldl, uint32_t flags, hipStream_t s) {
   // x is already multiplied by the frame mask at the end of every block (ar_discrete.py:161,773)
@@ -477,7 +490,6 @@ static int sample_loop_impl(const d3pm_shape* sh, const d3pm_weights* w, int bat
   for (int t = t_start; t > t_stop; --t) {
     g_prof.sample_now = (t % g_prof.stride) == 0;
     D3PM_TRY(denoiser_blocks(*sh, *w, batch, x, frame_mask, t, film, kv_text, kv_prompt, ws, sh->n_layers, flags, s, f8));
-    D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, logits_ld(*sh), flags, s));
     SampleArgs a;
     a.logits = ws.logits; a.logits_dtype = sh->dtype; a.ldl = logits_ld(*sh); a.x_t = x; a.x_next = x;
     a.x_next2 = trace ? trace + static_cast<size_t>(t_start - t) * rows : nullptr;
@@ -485,7 +497,14 @@ static int sample_loop_impl(const d3pm_shape* sh, const d3pm_weights* w, int bat
     if (flags & D3PM_FLAG_SEED_IN_HBM) a.seed_hbm = reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(seed));
     a.row0 = utt0 * static_cast<uint32_t>(sh->canvas); a.greedy = (flags & D3PM_FLAG_GREEDY) ? 1 : 0;
     a.pc = make_posterior_consts(sched, t);
-    {
+    const double fin_flops = 2.0 * rows * sh->n_classes * sh->d_model;
+    if (fused_final_sample_applies(*sh, *w, ws, flags)) {
+      // final projection + posterior + draw in one kernel: the logits stay on chip (d3pm_final_sample.hip)
+      ProfScope p(D3PM_K_SAMPLE, s, fin_flops,
+                  dtype_size(sh->dtype) * (static_cast<double>(rows) * sh->d_model + static_cast<double>(sh->n_classes) * sh->d_model) + 8.0 * rows);
+      D3PM_TRY(final_sample(sh->dtype, ws.x, sh->d_model, w->final_w, w->final_b, sh->d_model, a, s));
+    } else {
+      D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, logits_ld(*sh), flags, s));
       ProfScope p(D3PM_K_SAMPLE, s, 0.0,
                   static_cast<double>(rows) * (sh->n_classes * dtype_size(sh->dtype) + 8.0));
       D3PM_TRY(posterior_sample(a, s));
@@ -679,11 +698,28 @@ int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const vo
   return run_layernorm(dtype, ln, 0, static_cast<hipStream_t>(stream));
 }
 
+int d3pm_op_final_sample(const d3pm_shape* sh, const d3pm_weights* w, int batch, const void* hidden, const int32_t* x_t,
+                         int32_t* x_next, int t, const d3pm_schedule* sched, uint64_t seed, uint32_t utt0, uint32_t flags,
+                         void* stream) {
+  D3PM_TRY(check_shape(sh, batch));
+  D3PM_REQUIRE(w && w->final_w && hidden && x_t && x_next && sched && sched->d && sched->c && sched->dbar && sched->cbar, D3PM_E_ARG,
+               "d3pm_op_final_sample: null pointer");
+  D3PM_REQUIRE(t >= 0 && t < sched->timesteps, D3PM_E_ARG, "t=%d outside the schedule", t);
+  D3PM_REQUIRE(final_sample_supported(sh->dtype, sh->n_classes, sh->d_model, hidden, sh->d_model, w->final_w), D3PM_E_SHAPE,
+               "d3pm_op_final_sample: needs a 16-bit model, 1025 classes and d_model a multiple of 32 (<= 1024)");
+  SampleArgs a;
+  a.x_t = x_t; a.x_next = x_next; a.rows = batch * sh->canvas; a.n_classes = sh->n_classes; a.mask_id = sh->mask_id;
+  a.canvas = sh->canvas; a.seed = seed; a.row0 = utt0 * static_cast<uint32_t>(sh->canvas);
+  a.greedy = (flags & D3PM_FLAG_GREEDY) ? 1 : 0; a.pc = make_posterior_consts(sched, t);
+  return final_sample(sh->dtype, hidden, sh->d_model, w->final_w, w->final_b, sh->d_model, a, static_cast<hipStream_t>(stream));
+}
+
 int d3pm_set_tuning(int knob, int value) {
-  if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || value == 2 || value == 3 || value == 5 || (value >= 6 && value <= 8))) { set_gemm_variant(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || (value >= 2 && value <= 8))) { set_gemm_variant(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && value >= 0 && value <= 2) { set_attn_qg(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && (value == 0 || value == 1)) { set_attn_pair_sequential(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 9 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465)) { set_big_gemm_mode(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_FUSED_FINAL_SAMPLE && (value == 0 || value == 1)) { g_fused_final_sample = value; return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_PERSIST_SLOTS && value >= 8 && value <= 4096 && value % 8 == 0) { set_gemm_persist_slots(value); return D3PM_OK; }
   set_error("d3pm_set_tuning: unknown knob %d / value %d", knob, value);
   return D3PM_E_ARG;

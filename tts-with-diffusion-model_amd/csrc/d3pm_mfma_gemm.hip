@@ -347,13 +347,16 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
-// 0 auto, 2 throughput (128 x 128 persistent over whole tiles), 3 latency, 5 throughput with one 128 x 128 tile per workgroup,
+// 0 auto, 2 throughput (128 x 128 persistent over whole tiles), 3 the round-1 latency schedule (128 x 128, two stages), 4 the
+// latency schedule (64 x 64 tiles, whole-K panels), 5 throughput with one 128 x 128 tile per workgroup,
 // 6 / 7 / 8 big tiles (192 x 256 / 96 x 512 / 192 x 128, d3pm_mfma_gemm_big.hip) wherever they apply, else as auto without big tiles
 static int g_gemm_variant = 0;
 static int g_persist_slots = 1024;   // resident workgroups of the persistent schedule: 4 per CU x 256 CUs
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_gemm_persist_slots(int v) { g_persist_slots = v; }
 
+bool panel64_linear_supported(int dtype, const LinearArgs& a);
+int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s);
 int big_linear_tile(int dtype, const LinearArgs& a, int want);
 int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s);
 
@@ -365,6 +368,8 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
     const int id = big_linear_tile(dtype, a, g_gemm_variant == 6 ? 2 : g_gemm_variant == 7 ? 1 : g_gemm_variant == 8 ? 3 : 0);
     if (id) return big_linear(dtype, a, id, s);
   }
+  // one or two utterances: 64 x 64 tiles with whole-K panels in flight (d3pm_mfma_gemm_lat.hip); 4 forces it for any M
+  if ((g_gemm_variant == 4 || (autosel && a.M <= 1536)) && panel64_linear_supported(dtype, a)) return panel64_linear(dtype, a, s);
   const bool latency = !ffn_act && (g_gemm_variant == 3 || (autosel && a.M <= 1536));
   const int n_tiles = (a.N + BN - 1) / BN, m_tiles = (a.M + BM - 1) / BM;
   // shapes made of whole tiles go through the persistent kernel once there are enough tiles to fill the chip twice

@@ -1,0 +1,168 @@
+// d3pm_mfma_gemm_lat.hip -- latency GEMM for one or two utterances (M <= 1536 rows): 64 x 64 tiles, whole-K panels.
+//
+//   Y[M][N] = epilogue(X[M][K] . W[N][K]^T + bias)      same contract and epilogue as d3pm_mfma_gemm.hip
+//
+// replaces the nn.Linear / MultiheadAttention projections of DiTBlock.forward
+// (/root/reference/vall_e/vall_e/ar_discrete.py:132,138,142,159,776) when ONE utterance is sampled (the p50-latency
+// half of the BASELINE.json metric).  At M = 768 every 128 x 128 launch costs ~10 us whatever its size
+// (profiles/round1_i_microbench.txt): 24 .. 72 workgroups on 256 CUs, each walking its eight k-steps one DMA round
+// trip after the other.  The time is latency, so this kernel removes the chain instead of shortening its links:
+//   * 64 x 64 output tiles: 96 .. 384 workgroups for the block's projections at M = 768;
+//   * the operand panels of a tile for 256 k (X [64][256] + W [64][256] = 64 KiB) fit one LDS buffer, and there are two:
+//     for K = 512 EVERY DMA piece of the tile is issued before the first wait (32 per wave, all in flight together),
+//     so the kernel pays one memory round trip, not eight; longer K (fc2: 2048) streams 256-k rounds through the
+//     two buffers;
+//   * within a round the four k-steps run back to back, no barriers (the whole round has landed);
+//   * same swizzled 128-byte-row LDS image per 64-k sub-tile, same D = W_frag . X_frag^T orientation, same k order
+//     and the same epilogue code as the other schedules: bit-identical results.
+#include "d3pm_kernels.h"
+#include "d3pm_mfma_tile.h"
+
+namespace d3pm {
+namespace {
+
+constexpr int LT = 64;                       // tile rows and columns
+constexpr int KC = 256;                      // k per round
+constexpr int SUB_BYTES = LT * ROW_BYTES;    // one [64][64 k] sub-tile: 8 KiB
+constexpr int OPER_BYTES = (KC / BK) * SUB_BYTES;   // one operand of a round: 32 KiB
+constexpr int BUF_BYTES = 2 * OPER_BYTES;    // X + W of a round: 64 KiB
+
+__device__ __forceinline__ int xcd_remap_lat(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict__ X, int ldx, const T* __restrict__ W,
+                                                            const T* __restrict__ bias, T* Y, int ldy, const T* R1,
+                                                            const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
+                                                            int mask_period, int M, int N, int K, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = xcd_remap_lat(blockIdx.x, gridDim.x);
+  const int m0 = (bid / n_tiles) * LT, n0 = (bid % n_tiles) * LT;
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+  // DMA piece (sub-tile s, rows 8j .. 8j+7): a wave takes j = wave and wave + 4 of every sub-tile of both operands
+  // (swizzle key (row >> 1) & 7 = (4 (j & 1) + (lane >> 4)) & 7: two parities -> two per-lane offsets per operand)
+  const int lrow = lane >> 3;
+  const T* gx[2];
+  const T* gw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = wave + 4 * i, row = 8 * j + lrow;
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    int mr = m0 + row, nr = n0 + row;
+    mr = mr < M ? mr : M - 1;                // ragged edges: clamped loads, predicated stores
+    nr = nr < N ? nr : N - 1;
+    gx[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
+    gw[i] = W + static_cast<size_t>(nr) * K + logical * 8;
+  }
+  auto issue_round = [&](int r, int buf) {   // 16 pieces per wave
+    const uint32_t base = lds_base + buf * BUF_BYTES;
+#pragma unroll
+    for (int s = 0; s < KC / BK; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int j = wave + 4 * i;
+        glds16_asm(gx[i] + r * KC + s * BK, base + s * SUB_BYTES + j * 1024);
+        glds16_asm(gw[i] + r * KC + s * BK, base + OPER_BYTES + s * SUB_BYTES + j * 1024);
+      }
+  };
+  floatx4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fch = lane >> 4;
+  const int rounds = K / KC;                 // K is a multiple of 256 (launcher)
+  issue_round(0, 0);
+  if (rounds > 1) issue_round(1, 1);
+  for (int r = 0; r < rounds; ++r) {
+    const int buf = r & 1;
+    if (r + 1 < rounds) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the next round's 16 pieces may stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // every wave's pieces of round r have landed
+    __builtin_amdgcn_sched_barrier(0);
+    const char* bx = smem + buf * BUF_BYTES;
+    const char* bw = bx + OPER_BYTES;
+#pragma unroll
+    for (int s = 0; s < KC / BK; ++s)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 fx[2], fw[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          fx[q] = *reinterpret_cast<const uint4*>(bx + s * SUB_BYTES + lds_off(wm * 32 + q * 16 + frow, ks * 4 + fch));
+          fw[q] = *reinterpret_cast<const uint4*>(bw + s * SUB_BYTES + lds_off(wn * 32 + q * 16 + frow, ks * 4 + fch));
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (r + 2 < rounds) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // every wave has finished reading this buffer
+      issue_round(r + 2, buf);
+    }
+  }
+  epilogue_store<T, EPI, 2, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 32, n0 + wn * 32, lane);
+}
+
+inline bool aligned16l(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
+
+}  // namespace
+
+bool panel64_linear_supported(int dtype, const LinearArgs& a) {
+  if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
+  if (a.M < 1 || a.N < 16 || a.K < KC || a.K % KC != 0) return false;
+  if (a.ldx % 8 != 0 || a.ldy % 8 != 0 || !aligned16l(a.X) || !aligned16l(a.W) || !aligned16l(a.Y)) return false;
+  if (a.R1 && (a.ldr % 8 != 0 || a.N % 8 != 0 || !aligned16l(a.R1))) return false;
+  if (a.R2 && (!a.R1 || !aligned16l(a.R2))) return false;
+  const bool gelu = a.act == ACT_GELU, r1 = a.R1 != nullptr, r2 = a.R2 != nullptr, mk = a.row_mask != nullptr;
+  if (a.act != ACT_NONE && !gelu) return false;
+  if (gelu && (r1 || mk)) return false;       // instantiated epilogues: plain, GELU, R1, R1+R2, R1+mask
+  if (mk && (!r1 || r2)) return false;
+  return true;
+}
+
+int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s) {
+  const int n_tiles = (a.N + LT - 1) / LT, m_tiles = (a.M + LT - 1) / LT;
+  const dim3 grid(static_cast<unsigned>(n_tiles * m_tiles)), block(256);
+  const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
+#define D3PM_LAT(E)                                                                                                     \
+  do {                                                                                                                  \
+    static bool attr_set = false;                                                                                       \
+    if (!attr_set) {                                                                                                    \
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_panel64<U, E>),                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES));                   \
+      attr_set = true;                                                                                                  \
+    }                                                                                                                   \
+    gemm_mfma_panel64<U, E><<<grid, block, 2 * BUF_BYTES, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), \
+        static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy, static_cast<const U*>(a.R1),                       \
+        static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles);                         \
+    return D3PM_OK;                                                                                                     \
+  } while (0)
+  auto go = [&](auto* tag) -> int {
+    using U = std::remove_pointer_t<decltype(tag)>;
+    switch (epi) {
+      case 0: D3PM_LAT(0);
+      case EPI_GELU: D3PM_LAT(EPI_GELU);
+      case EPI_R1: D3PM_LAT(EPI_R1);
+      case EPI_R2: D3PM_LAT(EPI_R2);
+      case EPI_R1 | EPI_MASK: D3PM_LAT(EPI_R1 | EPI_MASK);
+      default: break;
+    }
+    return D3PM_E_SHAPE;
+  };
+#undef D3PM_LAT
+  int rc = dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
+  if (rc != D3PM_OK) return rc;
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+}  // namespace d3pm

@@ -20,16 +20,10 @@
 #include <cmath>
 
 #include "d3pm_kernels.h"
+#include "d3pm_sample_row.h"
 
 namespace d3pm {
 namespace {
-
-constexpr int kMaxGroupsPerLane = 5;   // supports n_classes <= 64*5*4 = 1280
-constexpr float kEps = 1.0e-6f;        // self.eps (ar_discrete.py:276), added in fp32 opmath then rounded
-
-template <typename T> __device__ __forceinline__ float load_logit16(const void* base, size_t idx) {
-  return rn16(static_cast<float>(static_cast<const T*>(base)[idx]));
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void posterior_sample_rows(
@@ -40,82 +34,9 @@ __global__ __launch_bounds__(256) void posterior_sample_rows(
   const int row = blockIdx.x * (blockDim.x >> 6) + wave;
   if (row >= rows) return;
   if (seed_hbm) seed = *seed_hbm;
-  const T* lr = logits + static_cast<size_t>(row) * ldl;
-  const int groups = (K + 3) >> 2;
-  float z[kMaxGroupsPerLane][4];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < kMaxGroupsPerLane; ++i) {
-    int g = lane + i * kWave;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      int j = g * 4 + w;
-      float v = (g < groups && j < K) ? rn16(static_cast<float>(lr[j])) : -INFINITY;
-      z[i][w] = v;
-      mx = fmaxf(mx, v);
-    }
-  }
-  const int x = x_t[row];
-  int best_j = 0;
-  float best_v = -INFINITY;
-  if (pc.t == 0) {
-    // t == 0: model logits are used as they are and no noise is added (ar_discrete.py:407,413)
-#pragma unroll
-    for (int i = 0; i < kMaxGroupsPerLane; ++i)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        int j = (lane + i * kWave) * 4 + w;
-        if (j < K && z[i][w] > best_v) { best_v = z[i][w]; best_j = j; }
-      }
-  } else {
-    mx = wave_max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < kMaxGroupsPerLane; ++i)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        float e = expf(z[i][w] - mx);   // exp(-inf) = 0 for the padding classes
-        z[i][w] = e;
-        sum += e;
-      }
-    sum = wave_sum(sum);
-    float s_other = 0.f, p_mask = 0.f;
-#pragma unroll
-    for (int i = 0; i < kMaxGroupsPerLane; ++i)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        int j = (lane + i * kWave) * 4 + w;
-        float p = rn16(z[i][w] / sum);
-        z[i][w] = p;
-        if (j == mask_id) p_mask = p; else s_other += p;
-      }
-    s_other = wave_sum(s_other);
-    p_mask = wave_sum(p_mask);
-    const float f2_mask = rn16(fmaf(s_other, pc.cbar_prev, p_mask));
-    const bool x_is_mask = (x == mask_id);
-#pragma unroll
-    for (int i = 0; i < kMaxGroupsPerLane; ++i) {
-      int g = lane + i * kWave;
-      if (g >= groups) continue;
-      float u[4];
-      if (!greedy) noise4(seed, static_cast<uint32_t>(g), row0 + static_cast<uint32_t>(row),
-                          static_cast<uint32_t>(pc.t), 0u, u);
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        int j = g * 4 + w;
-        if (j >= K) continue;
-        float lf1 = x_is_mask ? (j == mask_id ? pc.log_f1_one : pc.log_f1_c)
-                              : (j == x ? pc.log_f1_d : pc.log_f1_zero);
-        float f2 = (j == mask_id) ? f2_mask : rn16(z[i][w] * pc.dbar_prev);
-        float lf2 = rn16(logf(rn16(f2 + kEps)));
-        float out = rn16(lf1 + lf2);
-        if (post_out) post_out[static_cast<size_t>(row) * K + j] = __builtin_bit_cast(uint16_t, static_cast<f16>(out));
-        float v = greedy ? out : out + gumbel(u[w]);
-        if (v > best_v) { best_v = v; best_j = j; }   // ascending j per lane keeps the first maximum
-      }
-    }
-  }
-  wave_argmax(best_v, best_j);
+  const int best_j = sample_row<T>(logits + static_cast<size_t>(row) * ldl, K, mask_id, x_t[row], seed,
+                                   row0 + static_cast<uint32_t>(row), greedy, pc,
+                                   post_out ? post_out + static_cast<size_t>(row) * K : nullptr, lane);
   if (lane == 0) {
     x_next[row] = best_j;
     if (x_next2) x_next2[row] = best_j;

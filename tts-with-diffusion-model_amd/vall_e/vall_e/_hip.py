@@ -135,6 +135,8 @@ SIGNATURES = {
     "d3pm_op_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_float, C.c_void_p]),
     "d3pm_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "d3pm_op_final_sample": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
     "d3pm_debug_gemm_clock": (C.c_int, [C.POINTER(C.c_uint64)]),
     "d3pm_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "d3pm_prof_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -415,6 +417,17 @@ class Sampler:
                                           _p(post), stream_ptr()), "d3pm_posterior_sample")
         return x_next, post
 
+    def final_sample(self, hidden, x_t, t, seed, utt0=0, flags=0):
+        """hidden [B, canvas, d] (masked) -> x_{t-1} int32 [B, canvas] through the fused final + sampler kernel."""
+        cfg = self.cfg
+        B = self._check_grid(x_t)
+        _require(hidden, "hidden", (B, cfg.canvas, cfg.d_model), (self.dtype,), self.device)
+        x_next = torch.empty_like(x_t)
+        check(lib().d3pm_op_final_sample(C.byref(self.shape), C.byref(self.weights.c_struct), B, _p(hidden), _p(x_t), _p(x_next),
+                                         int(t), C.byref(self.schedule.c_struct), seed, utt0, flags, stream_ptr()),
+              "d3pm_op_final_sample")
+        return x_next
+
     def sample_loop(self, x, frame_mask, t_start, t_stop, kv_t, kv_p, seed, utt0=0, flags=0, trace=False, slot=0,
                     fp8=False):
         cfg = self.cfg
@@ -626,6 +639,10 @@ def set_attn_query_groups(v: int):
 
 def set_attn_pair_sequential(v: bool):
     check(lib().d3pm_set_tuning(3, 1 if v else 0), "d3pm_set_tuning")
+
+
+def set_fused_final_sample(v: bool):
+    check(lib().d3pm_set_tuning(5, 1 if v else 0), "d3pm_set_tuning")
 
 
 def set_gemm_big_mode(v: int):
