@@ -321,6 +321,9 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *                         problems in every workgroup, one after the other; 0 = the second half of the grid takes problem 2.
  * D3PM_TUNE_GEMM_PERSIST_SLOTS: resident workgroups of the persistent throughput schedule, a multiple of 8
  *                         (default 1024 = 4 per CU).
+ * D3PM_TUNE_ATTN_CROSS_RESIDENT: 1 (default) = the text + prompt cross-attention pair of a block (<= 64 and <= 256 keys) runs
+ *                         with every K / V tile of both problems fetched into LDS at kernel entry (one wait, no per-tile
+ *                         barrier, 256 queries per workgroup); 0 = the tile-by-tile kernel.  Same results.
  * D3PM_TUNE_FUSED_FINAL_SAMPLE: 1 = inside d3pm_sample_loop the final projection, the posterior and the draw are one
  *                         kernel and the logits never reach HBM (16-bit model, d_model a multiple of 32, MFMA family);
  *                         0 (default: measured faster) = the two-launch form (final GEMM, then d3pm_posterior_sample's
@@ -330,7 +333,8 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *                         >= 16 = timing-only ablation builds for tests/ab_gemm.py (WRONG results; bits: 16 no DMA, 32 no
  *                         MFMA, 64 no barriers, 128 no LDS reads, 256 clock stamp for d3pm_debug_gemm_clock). */
 enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2,
-       D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4, D3PM_TUNE_FUSED_FINAL_SAMPLE = 5 };
+       D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4, D3PM_TUNE_FUSED_FINAL_SAMPLE = 5,
+       D3PM_TUNE_ATTN_CROSS_RESIDENT = 6 };
 int d3pm_set_tuning(int knob, int value);
 
 /* Single-op entry of the fused final projection + posterior + draw (replaces `final` at ar_discrete.py:776 followed by

@@ -332,3 +332,32 @@ def test_sample_loop_is_the_same_with_and_without_the_fused_final_kernel(built_l
     finally:
         _hip.set_fused_final_sample(False)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("config", ["libritts", "wide448"])
+def test_cross_attention_pair_resident_kernel_equals_the_tile_by_tile_kernel(built_lib, dtype, config):
+    """attn_cross_hd64 (all K / V tiles of the text and prompt problems resident in LDS) runs the per-tile arithmetic of
+    attn_mfma_hd64 in the same order: a denoise step must give the same hidden state and logits bit for bit, for whole
+    and ragged key tiles (50 / 225 keys; 50 / 398 keys does not fit and must fall back) and a canvas that is not a multiple
+    of the 256-query block (448)."""
+    from vall_e.vall_e import AR, _hip, synth
+    cfg = synth.D3PMConfig.libritts() if config == "libritts" else synth.D3PMConfig(d_model=512, n_heads=8, n_layers=2, s_prompt=200)
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0))
+    m = m.to(dtype).to(DEV)
+    smp = m.sampler()
+    texts, proms = synth.make_inputs(cfg, 3, 1)
+    ct, cp = m.encode_conditions(texts, proms)
+    kv_t, kv_p = smp.cond_kv(ct, cp)
+    x, fm = m.canvas_init(3)
+    x[:, ::2] = torch.randint(0, 1024, x[:, ::2].shape, device=x.device, dtype=x.dtype)
+    outs = []
+    try:
+        for on in (False, True):
+            _hip.set_attn_cross_resident(on)
+            lg, hid = smp.denoise(x, fm, 30, kv_t, kv_p, want_hidden=True)
+            outs.append((lg.clone(), hid.clone()))
+    finally:
+        _hip.set_attn_cross_resident(True)
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])

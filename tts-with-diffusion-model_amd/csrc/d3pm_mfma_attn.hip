@@ -281,6 +281,184 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
   }   // problems of a sequential pair
 }
 
+// ---- cross-attention pair with short key sequences: attn_cross_hd64 ---------------------------------------------------
+// The text (<= 64 keys) and prompt (<= 256 keys) cross-attentions of a DiT block (ar_discrete.py:138,142) are two tiny
+// problems per query block: at B = 32 the tile-by-tile kernel above spends 49 us on 13.8 GFLOP (measured in situ) -- five
+// dependent load -> LDS -> barrier rounds per workgroup at two workgroups per CU, i.e. pure latency.  Here EVERY K / V tile of
+// both problems (<= 80 KiB) is fetched into LDS by direct-to-LDS DMA at kernel entry, all pieces in flight at once, the
+// workgroup waits once and then runs the five tiles back to back with no further barrier.  Eight waves x 32 queries share
+// the tiles (256 queries per workgroup).  Arithmetic per tile is the code of attn_mfma_hd64 (same rounding, same order).
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ Q1, const T* __restrict__ K1, const T* __restrict__ V1,
+                                                          T* __restrict__ O1, int S1, const T* __restrict__ Q2,
+                                                          const T* __restrict__ K2, const T* __restrict__ V2, T* __restrict__ O2,
+                                                          int S2, int ldq, int ldkv, int ldo, int Tq, float scale, int H,
+                                                          int n_qblocks) {
+  constexpr int QG = 2, MAXT = 5;                            // 1 text tile + up to 4 prompt tiles
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [tile][K | V], 16 KiB per tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid;
+  {
+    const int nblocks = gridDim.x, q = nblocks >> 3, r = nblocks & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int qb = bid % n_qblocks, h = (bid / n_qblocks) % H, b = bid / (n_qblocks * H);
+  const int nt2 = (S2 + BKV - 1) / BKV, n_tiles = 1 + nt2;
+  // ---- every K / V piece of both problems: 16 pieces (1 KiB = 8 rows x 128 B) per tile, dealt over the 8 waves
+  {
+    const int lrow = lane >> 3, cpos = lane & 7;
+    const int total = n_tiles * 16;
+    for (int p = wave; p < total; p += 8) {                 // wave-uniform trip count
+      const int tile = p >> 4, which = (p >> 3) & 1, j = p & 7;   // which: 0 = K, 1 = V
+      const int row = 8 * j + lrow;
+      const int logical = which == 0 ? (cpos ^ ((row >> 1) & 7)) : (cpos ^ (((row >> 1) & 3) << 1));
+      const T* base = tile == 0 ? (which == 0 ? K1 : V1) : (which == 0 ? K2 : V2);
+      const int S = tile == 0 ? S1 : S2;
+      int key = (tile == 0 ? 0 : (tile - 1) * BKV) + row;
+      key = key < S ? key : S - 1;
+      const T* src = base + (static_cast<size_t>(b) * S + key) * ldkv + h * HD + logical * 8;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(smem + tile * 2 * TILE + which * TILE + j * 1024), 16, 0, 0);
+    }
+  }
+  const int q0 = (qb * 8 + wave) * (16 * QG);
+  const int qi = lane & 15, g = lane >> 4;
+  const float qscale = scale * 1.4426950408889634f;
+  const uint32_t one2 = pack2<T>(1.0f, 1.0f);
+  const uint4 ones = uint4{one2, one2, one2, one2};
+  bool landed = false;
+  for (int prob = 0; prob < 2; ++prob) {
+    const T* Q = prob == 0 ? Q1 : Q2;
+    T* O = prob == 0 ? O1 : O2;
+    const int S = prob == 0 ? S1 : S2, t0 = prob == 0 ? 0 : 1, nt = prob == 0 ? 1 : nt2;
+    uint4 qf[QG][2];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+      int qrow = q0 + qg * 16 + qi;
+      qrow = qrow < Tq ? qrow : Tq - 1;
+      const T* qp = Q + (static_cast<size_t>(b) * Tq + qrow) * ldq + h * HD;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        typedef T tvec8 __attribute__((ext_vector_type(8)));
+        const tvec8 e = __builtin_bit_cast(tvec8, *reinterpret_cast<const uint4*>(qp + ks * 32 + g * 8));
+        qf[qg][ks] = uint4{pack2<T>(static_cast<float>(e[0]) * qscale, static_cast<float>(e[1]) * qscale),
+                           pack2<T>(static_cast<float>(e[2]) * qscale, static_cast<float>(e[3]) * qscale),
+                           pack2<T>(static_cast<float>(e[4]) * qscale, static_cast<float>(e[5]) * qscale),
+                           pack2<T>(static_cast<float>(e[6]) * qscale, static_cast<float>(e[7]) * qscale)};
+      }
+    }
+    if (!landed) {                                           // one wait for the whole workgroup's K / V image
+      __syncthreads();                                       // (drains this wave's DMA pieces, then the barrier)
+      landed = true;
+    }
+    float m_ref[QG];
+    floatx4 negm[QG], acc_o[QG][4], acc_l[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+      m_ref[qg] = 0.f;
+      negm[qg] = floatx4{0.f, 0.f, 0.f, 0.f};
+      acc_l[qg] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) acc_o[qg][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int tile = 0; tile < nt; ++tile) {
+      const char* kb = smem + (t0 + tile) * 2 * TILE;
+      const char* vb = kb + TILE;
+      floatx4 s[QG][4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          uint4 kf = *reinterpret_cast<const uint4*>(kb + k_off(kt * 16 + qi, ks * 4 + g));
+#pragma unroll
+          for (int qg = 0; qg < QG; ++qg) s[qg][kt] = mma<T>(kf, qf[qg][ks], ks == 0 ? negm[qg] : s[qg][kt]);
+        }
+      const bool ragged = (tile == nt - 1) && (S & (BKV - 1));
+      const int key_base = tile * BKV + 4 * g;
+      uint4 pf[QG][2];
+#pragma unroll
+      for (int qg = 0; qg < QG; ++qg) {
+        if (ragged) {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[qg][kt][r] = (key_base + kt * 16 + r < S) ? s[qg][kt][r] : -INFINITY;
+        }
+        float mx = fmaxf(s[qg][0][0], s[qg][0][1]);
+        mx = fmaxf(fmaxf(mx, s[qg][0][2]), s[qg][0][3]);
+#pragma unroll
+        for (int kt = 1; kt < 4; ++kt) {
+          mx = fmaxf(fmaxf(mx, s[qg][kt][0]), s[qg][kt][1]);
+          mx = fmaxf(fmaxf(mx, s[qg][kt][2]), s[qg][kt][3]);
+        }
+        if (tile == 0 || __any(mx > kDefer)) {
+          mx = max_over_query_lanes(mx);
+          const float delta = tile == 0 ? mx : fmaxf(mx, 0.f);
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[qg][kt][r] -= delta;
+          if (tile != 0) {
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_l[qg][r] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc_o[qg][dt][r] *= alpha;
+          }
+          m_ref[qg] += delta;
+          negm[qg] = floatx4{-m_ref[qg], -m_ref[qg], -m_ref[qg], -m_ref[qg]};
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[qg][kt][r] = __builtin_amdgcn_exp2f(s[qg][kt][r]);
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+          const floatx4 pa = s[qg][2 * kb2], pb = s[qg][2 * kb2 + 1];
+          pf[qg][kb2] = uint4{pack2<T>(pa[0], pa[1]), pack2<T>(pa[2], pa[3]), pack2<T>(pb[0], pb[1]), pack2<T>(pb[2], pb[3])};
+        }
+      }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int col = dt * 16 + 4 * (qi & 3);
+          const int r0 = (2 * kb2) * 16 + 4 * g + (qi >> 2), r1 = r0 + 16;
+          typedef short4v __attribute__((address_space(3))) * lds_ptr;
+          short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + v_off(r0, col >> 3) + (col & 7) * 2));
+          short4v vc = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + v_off(r1, col >> 3) + (col & 7) * 2));
+          uint2 lo = __builtin_bit_cast(uint2, va), hi = __builtin_bit_cast(uint2, vc);
+          const uint4 vf = uint4{lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+          for (int qg = 0; qg < QG; ++qg) acc_o[qg][dt] = mma<T>(vf, pf[qg][kb2], acc_o[qg][dt]);
+        }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) acc_l[qg] = mma<T>(ones, pf[qg][kb2], acc_l[qg]);
+    }
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+      const float inv = 1.0f / acc_l[qg][0];
+      const int qrow = q0 + qg * 16 + qi;
+      if (qrow < Tq) {
+        T* op = O + (static_cast<size_t>(b) * Tq + qrow) * ldo + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          uint2 o{pack2<T>(acc_o[qg][dt][0] * inv, acc_o[qg][dt][1] * inv), pack2<T>(acc_o[qg][dt][2] * inv, acc_o[qg][dt][3] * inv)};
+          *reinterpret_cast<uint2*>(op + dt * 16 + 4 * g) = o;
+        }
+      }
+    }
+  }
+  (void)MAXT;
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -301,7 +479,31 @@ static bool g_attn_pair_seq = true;
 void set_attn_qg(int v) { g_attn_qg = v; }
 void set_attn_pair_sequential(int v) { g_attn_pair_seq = v != 0; }
 
+static int g_attn_cross_resident = 1;   // cross-attention pair with every K / V tile resident in LDS (attn_cross_hd64)
+void set_attn_cross_resident(int v) { g_attn_cross_resident = v; }
+
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
+  if (g_attn_cross_resident && a.Q2 != nullptr && a.key_len == nullptr && a.S <= BKV && a.S2 <= 4 * BKV) {
+    const int n_qblocks = (a.Tq + 255) / 256;
+    const dim3 grid(static_cast<unsigned>(n_qblocks * a.H * a.B)), block(512);
+    const size_t lds = static_cast<size_t>(1 + (a.S2 + BKV - 1) / BKV) * 2 * TILE;
+#define D3PM_CROSS(T)                                                                                                        \
+    do {                                                                                                                     \
+      static bool attr_set = false;                                                                                          \
+      if (!attr_set) {                                                                                                       \
+        D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_cross_hd64<T>),                               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 2 * TILE));                       \
+        attr_set = true;                                                                                                     \
+      }                                                                                                                      \
+      attn_cross_hd64<T><<<grid, block, lds, s>>>(static_cast<const T*>(a.Q), static_cast<const T*>(a.K),                     \
+          static_cast<const T*>(a.V), static_cast<T*>(a.O), a.S, static_cast<const T*>(a.Q2), static_cast<const T*>(a.K2),    \
+          static_cast<const T*>(a.V2), static_cast<T*>(a.O2), a.S2, a.ldq, a.ldkv, a.ldo, a.Tq, a.scale, a.H, n_qblocks);    \
+    } while (0)
+    if (dtype == D3PM_F16) D3PM_CROSS(f16); else D3PM_CROSS(bf16);
+#undef D3PM_CROSS
+    D3PM_LAUNCH_CHECK();
+    return D3PM_OK;
+  }
   const long long wgs2 = static_cast<long long>((a.Tq + 127) / 128) * a.H * a.B * (a.Q2 ? 2 : 1);
   const int qg = g_attn_qg == 0 ? (wgs2 >= 4 * 256 ? 2 : 1) : g_attn_qg, per_block = 64 * qg;
   const int n_qblocks = (a.Tq + per_block - 1) / per_block;

@@ -641,6 +641,10 @@ def set_attn_pair_sequential(v: bool):
     check(lib().d3pm_set_tuning(3, 1 if v else 0), "d3pm_set_tuning")
 
 
+def set_attn_cross_resident(v: bool):
+    check(lib().d3pm_set_tuning(6, 1 if v else 0), "d3pm_set_tuning")
+
+
 def set_fused_final_sample(v: bool):
     check(lib().d3pm_set_tuning(5, 1 if v else 0), "d3pm_set_tuning")
 
