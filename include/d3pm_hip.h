@@ -360,6 +360,45 @@ int d3pm_prof_read_class(int kclass, int *launches, double *total_ms, double *fl
 int d3pm_prof_read(int *launches, double *total_ms, double *flops, double *bytes);
 int d3pm_prof_disable(void);
 
+/* ---- Training side: gradients of the ops of AR.forward ------------------------------------------
+ * The reference obtains them from autograd over ar_discrete.py:588-694 (DiT blocks :126-161, final Linear :776, masked
+ * cross-entropy :683-690) inside engine.backward (utils/engines.py:144-147).  Here each is a single-op entry on fp32
+ * tensors (the F32 precision mode); vall_e/vall_e/train.py replays the forward with a stash and walks it backwards.
+ * All pointers are device pointers owned by the caller; nothing allocates or synchronises; 0 = ok.
+ *
+ * d3pm_op_matmul_f32      C[i][j] = beta C[i][j] + sum_k A[i sai + k sak] B[k sbk + j sbj]; rows of C whose row_mask entry
+ *                         (row % mask_period) is 0 receive 0 (+ beta C).  dX = dY W and dW += dY^T X of every nn.Linear.
+ * d3pm_op_colsum_f32      out[j] = beta out[j] + sum_i X[i][j]                              (bias gradients)
+ * d3pm_op_act_bwd_f32     dU = dM act'(U), act = 1 exact-erf GELU (nn.GELU, :123), 2 ReLU, 3 SiLU (condition encoders)
+ * d3pm_op_mask_rows_f32   X[i][:] = 0 where mask[i % period] == 0                           (x * mask, :128,161)
+ * d3pm_op_layernorm_bwd_f32  LayerNorm (+ FiLM out = y (1 + film[c]) + film[d + c], :145-156) backward of one [M][d] block:
+ *                         dX (overwritten or accumulated), dw / db / dfilm accumulated (fp32 atomics)
+ * d3pm_op_attention_bwd_f32  softmax(scale q k^T) v backward (nn.MultiheadAttention core, :132,138,142): dQ overwritten,
+ *                         dK / dV = beta_kv * old + new; stats = 2 B H Tq floats of scratch
+ * d3pm_op_ce_bwd_f32      dlogits = mask (softmax(logits mask) - onehot(target)) gscale    (:683-690)
+ * d3pm_op_embed_f32 / d3pm_op_embed_bwd_f32  nn.Embedding gather with the row mask, and its scatter-add (padding_idx row skipped) */
+/* The condition-side embeddings as a single op (ar_discrete.py:736-741): which = 0 text rows W[tok] + pe0 (`tables` [n_classes][d],
+ * `pe` [d]); which = 1 prompt rows sum_l W[l][tok_l] + pe[s] (`tokens` [rows][n_levels], -1 = level absent; `tables`
+ * [n_levels][n_classes][d]; `pe` [s_prompt][d]).  Used by the training step, which needs the encoder inputs it stashes. */
+int d3pm_op_cond_embed(int dtype, int which, const int32_t *tokens, int n_levels, const void *tables, const void *pe, void *y, int rows,
+                       int s_prompt, int d, int n_classes, void *stream);
+int d3pm_op_matmul_f32(const float *A, long sai, long sak, const float *B, long sbk, long sbj, float *C, int ldc, int M, int N, int K,
+                       float beta, const uint8_t *row_mask, int mask_period, void *stream);
+int d3pm_op_colsum_f32(const float *X, int ldx, int M, int N, float *out, float beta, void *stream);
+int d3pm_op_act_bwd_f32(const float *U, const float *dM, float *dU, size_t n, int act, void *stream);
+int d3pm_op_mask_rows_f32(float *X, int ldx, int M, int N, const uint8_t *mask, int period, void *stream);
+int d3pm_op_layernorm_bwd_f32(const float *X, const float *dOut, const float *w, const float *b, const float *film, float eps, int M,
+                              int d, float *dX, int accumulate_dx, float *dw, float *db, float *dfilm, void *stream);
+int d3pm_op_attention_bwd_f32(const float *Q, int ldq, const float *K, const float *V, int ldkv, const float *dO, int ldo, float *dQ,
+                              int lddq, float *dK, float *dV, int lddkv, float *stats, int B, int Tq, int S, int H, int hd, float scale,
+                              float beta_kv, void *stream);
+int d3pm_op_ce_bwd_f32(const float *logits, int ldl, const int32_t *targets, const uint8_t *frame_mask, int canvas, int rows, int K,
+                       float gscale, float *dlogits, int ldd, void *stream);
+int d3pm_op_embed_f32(const int32_t *tok, const uint8_t *mask, int period, const float *table, float *Y, int rows, int d, int n_classes,
+                      void *stream);
+int d3pm_op_embed_bwd_f32(const int32_t *tok, const uint8_t *mask, int period, const float *dY, float *dTable, int rows, int d,
+                          int n_classes, int padding_idx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

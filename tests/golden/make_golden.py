@@ -332,6 +332,72 @@ def gen_forward(out, m):
     np.savez_compressed(os.path.join(out, "native_forward.npz"), **fw)
 
 
+def gen_grads(out, m):
+    """Gradients of the reference's own training forward (ar_discrete.py:588-694) by torch.autograd, native shape, fp32, three
+    timesteps (instance attribute `timesteps = 4`, read at call time at :648): `self.loss.backward()` on the reference module.
+    torch.autograd over the oracle's training_forward must give the same gradients; the fixture keeps, per parameter, the sum,
+    the absolute sum and 8 strided samples of the gradient (the HIP backward is checked against them on the GPU)."""
+    cfg = synth.D3PMConfig.native()
+    shape = O.Shape.of(cfg)
+    sd32 = synth.make_state_dict(cfg, W_SEED)
+    texts, proms = synth.make_inputs(cfg, 1, IN_SEED)
+    m.float().load_state_dict(sd32)
+    resps = torch.from_numpy(np.load(os.path.join(out, "native_forward.npz"))["resps"].astype(np.int64))
+    seed, T = 31, 4
+
+    class QNoise:
+        def __init__(self):
+            self.t = 1
+        def __enter__(self):
+            self.orig = torch.rand
+            def rand(size=None, *a, **k):
+                u = torch.from_numpy(philox.uniform_batch(seed, self.t, 0, 1, cfg.canvas, stream=philox.STREAM_Q_SAMPLE))
+                self.t += 1
+                return u
+            torch.rand = rand
+            return self
+        def __exit__(self, *exc):
+            torch.rand = self.orig
+
+    def q_noise(t):
+        return torch.from_numpy(philox.uniform_batch(seed, t, 0, 1, cfg.canvas, stream=philox.STREAM_Q_SAMPLE))[0]
+
+    for p in m.parameters():
+        p.grad = None
+    m.timesteps = T
+    try:
+        with rh.cuda_strings_as_cpu(), QNoise(), contextlib.redirect_stdout(io.StringIO()):
+            m.forward([texts[0]], [proms[0]], [resps])
+            m.loss.backward()
+    finally:
+        m.timesteps = 100
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd32.items()}
+    loss_o, _ = O.training_forward(sd, shape, texts[0], proms[0], resps, q_noise, timesteps=T)
+    loss_o.backward()
+    assert torch.equal(m.loss.detach(), loss_o.detach()), (m.loss, loss_o)
+    res = {"seed": np.array(seed), "timesteps": np.array(T), "loss": np.array(float(m.loss.detach()), dtype=np.float64)}
+    names, n_checked = [], 0
+    for name, p in m.named_parameters():
+        if p.grad is None:
+            assert sd[name].grad is None or float(sd[name].grad.abs().max()) == 0.0, name
+            continue
+        go = sd[name].grad
+        if name in ("text_emb.weight", "resps_emb.weight"):      # nn.Embedding(padding_idx=0) (ar_discrete.py:210,212): row 0 gets no
+            go = go.clone()                                      # gradient upstream; the functional oracle has no padding_idx
+            go[0] = 0
+        # same forward values bit for bit; the two backward graphs sum in different orders (fp32): a few 1e-6 of the gradient scale
+        assert go is not None and (p.grad - go).abs().max() <= 5e-5 * p.grad.abs().max() + 1e-12, (name, (p.grad - go).abs().max(), p.grad.abs().max())
+        g = p.grad.reshape(-1).double()
+        idx = torch.linspace(0, g.numel() - 1, 8).long()
+        res["g/" + name] = np.concatenate([[g.sum().item(), g.abs().sum().item()], g[idx].numpy()])
+        names.append(name)
+        n_checked += 1
+    for p in m.parameters():
+        p.grad = None
+    np.savez_compressed(os.path.join(out, "native_grads.npz"), **res)
+    print(f"  grads: reference autograd == oracle autograd on {n_checked} tensors, loss {float(res['loss']):.6f}")
+
+
 def gen_wide(out, m):
     """Swap the reference's own classes in at d=512,H=8,L=6 (canvas stays the hard-coded 448/350)."""
     base, ard = rh.load_reference_modules()
@@ -490,6 +556,7 @@ def main():
     print("tables (200 steps) ..."); gen_tables_t200(out)
     print("native ..."); gen_native(out, m)
     print("forward ..."); gen_forward(out, m)
+    print("grads ...");  gen_grads(out, m)
     print("wide ...");   gen_wide(out, m)
     print("nar ...");    gen_nar(out)
     print("formats ..."); gen_formats(out)

@@ -97,3 +97,45 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vall_e.vall_e.train import all_reduce_gradients
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    for i, p in enumerate(model.parameters()):
+        if rank == 1 and i == 4:
+            continue                                      # a parameter that got no gradient on this rank: counts as zeros
+        p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+    n = all_reduce_gradients(model, bucket_bytes=80)     # tiny buckets: several collectives, tensors never split
+    out = [p.grad.flatten().tolist() for p in model.parameters()]     # plain lists: no shared-memory handles through the queue
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, n, out))
+
+
+def test_gradient_all_reduce_world2():
+    """The data-parallel gradient reduction of the training step (reference: DeepSpeed inside engine.backward,
+    utils/engines.py:144-147): bucketed SUM all-reduce / world size, identical collectives on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 431
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, g0), (_, n1, g1) = res
+    assert n0 == n1 and n0 > 1
+    for i, (a, b) in enumerate(zip(g0, g1)):
+        assert a == b
+        want = ((1 * (i + 1)) + (0 if i == 4 else 2 * (i + 1))) / 2.0
+        assert all(abs(v - want) < 1e-6 for v in a), (i, a[0], want)

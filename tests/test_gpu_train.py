@@ -1,0 +1,100 @@
+"""Training side: loss and parameter gradients of AR.forward from the HIP backward kernels against
+torch.autograd over the CPU oracle (oracle/d3pm_oracle.py:training_forward, pinned bit-for-bit to the reference's own
+forward(), tests/golden/native_forward.npz) -- upstream-native shape, fp32, same q_sample noise (Philox stream 1)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import d3pm_oracle as O
+from oracle import philox
+from util import REPORT, load, native_setup
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _oracle_grads(cfg, sd32, text, prom, resps, seed, T):
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd32.items()}
+
+    def q_noise(t):
+        return torch.from_numpy(philox.uniform_batch(seed, t, 0, 1, cfg.canvas, stream=philox.STREAM_Q_SAMPLE))[0]
+
+    loss, _ = O.training_forward(sd, O.Shape.of(cfg), text, prom, resps, q_noise, timesteps=T)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+def test_gradients_match_autograd_over_the_oracle():
+    from vall_e.vall_e import AR
+    from vall_e.vall_e.train import D3PMTrainer
+    cfg, sd32, texts, proms, _ = native_setup(torch.float32)
+    g = load("native_forward.npz")
+    resps = torch.from_numpy(g["resps"].astype(np.int64))
+    seed, T = int(g["seed"]), 4                                  # t = 1, 2, 3: three noised canvases, every kernel on the path
+    ref_loss, ref = _oracle_grads(cfg, sd32, texts[0], proms[0], resps, seed, T)
+    m = AR.reference_native()
+    m.load_state_dict(sd32)
+    m = m.float().to(DEV)
+    loss, dconds = D3PMTrainer(m).forward_backward([texts[0]], [proms[0]], [resps], seed=seed, timesteps=T)
+    assert abs(float(loss) - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (float(loss), ref_loss)
+    worst, checked = {}, 0
+    for name, p in m.named_parameters():
+        if ".cross_attn2." in name or name.startswith("token_emb"):
+            continue
+        want = ref.get(name)
+        got = p.grad
+        if want is None:                                        # a parameter the forward never reads (none expected here)
+            assert got is None or float(got.abs().max()) == 0.0, name
+            continue
+        assert got is not None, f"no gradient for {name}"
+        if name in ("text_emb.weight", "resps_emb.weight"):     # nn.Embedding(padding_idx=0) upstream: row 0 gets no gradient
+            want = want.clone()
+            want[0] = 0
+        err = (got.cpu() - want).abs().max().item()
+        scale = want.abs().max().item()
+        worst[name] = err / max(scale, 1e-8)
+        checked += 1
+        assert err <= 2e-4 * scale + 1e-7, f"{name}: max |grad error| {err:.3e} vs gradient scale {scale:.3e}"
+    # the reference's own autograd on its own forward (tests/golden/native_grads.npz, make_golden.py:gen_grads; same seed and T)
+    gold = load("native_grads.npz")
+    assert int(gold["seed"]) == seed and int(gold["timesteps"]) == T and abs(float(loss) - float(gold["loss"])) < 1e-5
+    n_gold = 0
+    for name, p in m.named_parameters():
+        key = "g/" + name
+        if key not in gold.files:
+            continue
+        flat = p.grad.cpu().reshape(-1).double()
+        idx = torch.linspace(0, flat.numel() - 1, 8).long()
+        want = gold[key]
+        scale = max(np.abs(want[2:]).max(), want[1] / flat.numel(), 1e-12)
+        assert np.abs(flat[idx].numpy() - want[2:]).max() <= 5e-4 * scale + 1e-9, (name, flat[idx].numpy(), want[2:])
+        assert abs(flat.abs().sum().item() - want[1]) <= 5e-4 * want[1] + 1e-9, (name, flat.abs().sum().item(), want[1])
+        n_gold += 1
+    assert n_gold >= 230
+    REPORT["train_gradcheck_native_f32"] = {"loss_hip": float(loss), "loss_autograd": ref_loss, "tensors_checked": checked,
+                                            "worst_relative_error": max(worst.values()), "worst_tensor": max(worst, key=worst.get)}
+    assert checked >= 230
+    for name, p in m.named_parameters():                        # dead upstream parameters stay gradient-free
+        if ".cross_attn2." in name or name.startswith("token_emb"):
+            assert p.grad is None
+    assert dconds[0][0].shape == (cfg.s_text, cfg.d_model) and float(dconds[0][1].abs().max()) > 0
+
+
+def test_one_optimizer_step_lowers_the_loss():
+    """forward_backward + torch.optim on the .grad it fills: the loss on the same batch and noise goes down."""
+    from vall_e.vall_e import AR
+    from vall_e.vall_e.train import D3PMTrainer
+    cfg, sd32, texts, proms, _ = native_setup(torch.float32)
+    resps = torch.from_numpy(load("native_forward.npz")["resps"].astype(np.int64))
+    m = AR.reference_native()
+    m.load_state_dict(sd32)
+    m = m.float().to(DEV)
+    tr = D3PMTrainer(m)
+    opt = torch.optim.SGD([p for n, p in m.named_parameters() if n.startswith(("blocks.", "final."))], lr=0.05)
+    l0, _ = tr.forward_backward([texts[0]], [proms[0]], [resps], seed=3, timesteps=3)
+    opt.step()
+    for p in m.parameters():
+        p.grad = None
+    l1, _ = tr.forward_backward([texts[0]], [proms[0]], [resps], seed=3, timesteps=3)
+    REPORT["train_sgd_step_loss"] = {"before": float(l0), "after": float(l1)}
+    assert float(l1) < float(l0)

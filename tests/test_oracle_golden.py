@@ -195,3 +195,33 @@ def test_training_forward_loss(tag, dtype):
 
 def g_rows():
     return load("native_step.npz")["rows"]
+
+
+def test_training_gradients_of_the_oracle_match_the_references_autograd():
+    """tests/golden/native_grads.npz: per-parameter gradient summaries from `loss.backward()` on the reference's own forward
+    (make_golden.py:gen_grads, three timesteps, fp32).  torch.autograd over the oracle must reproduce them -- this is the
+    checker the HIP backward kernels are compared with on the GPU (tests/test_gpu_train.py)."""
+    g = load("native_grads.npz")
+    cfg, sd32, texts, proms, _ = native_setup(torch.float32)
+    resps = torch.from_numpy(load("native_forward.npz")["resps"].astype(np.int64))
+    seed, T = int(g["seed"]), int(g["timesteps"])
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd32.items()}
+
+    def q_noise(t):
+        return torch.from_numpy(philox.uniform_batch(seed, t, 0, 1, cfg.canvas, stream=philox.STREAM_Q_SAMPLE))[0]
+
+    loss, _ = O.training_forward(sd, O.Shape.of(cfg), texts[0], proms[0], resps, q_noise, timesteps=T)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+    names = [k[2:] for k in g.files if k.startswith("g/")]
+    assert len(names) >= 230
+    for name in names:
+        grad = sd[name].grad.clone()
+        if name in ("text_emb.weight", "resps_emb.weight"):
+            grad[0] = 0                                   # nn.Embedding(padding_idx=0) upstream
+        flat = grad.reshape(-1).double()
+        idx = torch.linspace(0, flat.numel() - 1, 8).long()
+        want = g["g/" + name]
+        scale = max(np.abs(want[2:]).max(), want[1] / flat.numel(), 1e-12)
+        assert np.abs(flat[idx].numpy() - want[2:]).max() <= 1e-4 * scale + 1e-10, (name, flat[idx].numpy(), want[2:])
+        assert abs(flat.abs().sum().item() - want[1]) <= 1e-4 * want[1] + 1e-12, (name, flat.abs().sum().item(), want[1])

@@ -715,6 +715,15 @@ int d3pm_op_final_sample(const d3pm_shape* sh, const d3pm_weights* w, int batch,
   return final_sample(sh->dtype, hidden, sh->d_model, w->final_w, w->final_b, sh->d_model, a, static_cast<hipStream_t>(stream));
 }
 
+int d3pm_op_cond_embed(int dtype, int which, const int32_t* tokens, int n_levels, const void* tables, const void* pe, void* y, int rows,
+                       int s_prompt, int d, int n_classes, void* stream) {
+  D3PM_REQUIRE(tokens && tables && pe && y && rows > 0 && d > 0 && n_classes > 0, D3PM_E_ARG, "d3pm_op_cond_embed: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (which == 0) return cond_embed_text(dtype, tokens, tables, pe, y, rows, d, n_classes, s);
+  D3PM_REQUIRE(n_levels > 0 && s_prompt > 0, D3PM_E_ARG, "d3pm_op_cond_embed: bad prompt arguments");
+  return cond_embed_prompt(dtype, tokens, n_levels, tables, pe, y, rows, s_prompt, d, n_classes, s);
+}
+
 int d3pm_set_tuning(int knob, int value) {
   if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || (value >= 2 && value <= 8))) { set_gemm_variant(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && value >= 0 && value <= 2) { set_attn_qg(value); return D3PM_OK; }

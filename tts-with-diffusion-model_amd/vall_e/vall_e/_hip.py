@@ -134,6 +134,23 @@ SIGNATURES = {
                                     C.c_void_p]),
     "d3pm_op_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_float, C.c_void_p]),
+    "d3pm_op_cond_embed": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p]),
+    "d3pm_op_matmul_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "d3pm_op_colsum_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
+    "d3pm_op_act_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "d3pm_op_mask_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "d3pm_op_layernorm_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "d3pm_op_attention_bwd_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "d3pm_op_ce_bwd_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                     C.c_int, C.c_void_p]),
+    "d3pm_op_embed_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "d3pm_op_embed_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p]),
     "d3pm_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "d3pm_op_final_sample": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),

@@ -331,6 +331,17 @@ class AR(SymmapState, nn.Module):
         fm = mask.to(torch.uint8).contiguous()
         return smp.q_sample(x_start.to(torch.int32).contiguous(), fm, int(t.reshape(-1)[0]), seed, utt0).long()
 
+    def forward_backward(self, text_list, proms_list, resps_list, *, seed: Optional[int] = None, timesteps: Optional[int] = None):
+        """The training step's compute (reference: `engine.backward(engine(...))`, utils/engines.py:144-147 over
+        ar_discrete.py:588-694): the loss of `forward` AND its gradient for every parameter the forward reads, accumulated
+        into `param.grad` by the HIP backward kernels (vall_e/vall_e/train.py; fp32 model).  Follow it with
+        `train.all_reduce_gradients(self)` under torch.distributed and any torch.optim step.  Returns the loss."""
+        from .train import D3PMTrainer
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        loss, _ = D3PMTrainer(self).forward_backward(text_list, proms_list, resps_list, seed=seed, timesteps=timesteps)
+        return loss
+
     @torch.no_grad()
     def forward(self, text_list, proms_list, resps_list=None, spkr_name=None, *, seed: Optional[int] = None):
         """Training-side forward, evaluation only (forward half; ar_discrete.py:588-694): for every
@@ -338,8 +349,8 @@ class AR(SymmapState, nn.Module):
             loss = sum_{t=1}^{timesteps-1} mean_canvas CE(final(blocks(q_sample(x_0, t))) * mask, x_0 * mask) / mask.sum().
         Sets `self.loss` (mean over the utterances; upstream indexes `[0]` throughout, so for one utterance this is its
         value) and returns the masked logits of the last step of the last utterance, `[canvas, n_classes]`, as upstream.
-        q_sample draws Philox stream 1 keyed by `seed` instead of torch.rand.  No autograd graph is built: the backward
-        pass is not part of this build, the loss serves validation / parity."""
+        q_sample draws Philox stream 1 keyed by `seed` instead of torch.rand.  No autograd graph is built: gradients come from
+        `forward_backward` (hand-written backward kernels), not from torch.autograd."""
         if resps_list is None or not (len(text_list) == len(proms_list) == len(resps_list)) or len(text_list) == 0:
             raise ValueError("text_list, proms_list and resps_list must be non-empty and of equal length")
         smp = self.sampler()
