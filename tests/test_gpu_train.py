@@ -98,3 +98,39 @@ def test_one_optimizer_step_lowers_the_loss():
     l1, _ = tr.forward_backward([texts[0]], [proms[0]], [resps], seed=3, timesteps=3)
     REPORT["train_sgd_step_loss"] = {"before": float(l0), "after": float(l1)}
     assert float(l1) < float(l0)
+
+
+def test_rccl_world_size_1_gather_and_gradient_all_reduce():
+    """The data-path collectives on the real backend ("nccl" = RCCL on ROCm): one rank is all a single-GPU box allows, but it
+    loads RCCL, creates the communicator and runs the same all_gather_into_tensor / all_reduce calls dp.py and train.py
+    issue (the 2- and 3-rank logic is covered on gloo in tests/test_dp_gloo.py).  Child process: a process group must not
+    leak into the rest of the suite."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path[:0] = [os.path.join(os.environ['ROOT'], 'tts-with-diffusion-model_amd')]
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', RANK='0', WORLD_SIZE='1')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+from vall_e.vall_e import dp
+from vall_e.vall_e.train import all_reduce_gradients
+ids = torch.arange(2 * 16, dtype=torch.int32, device='cuda').reshape(2, 16)
+out = torch.empty_like(ids)
+dist.all_gather_into_tensor(out, ids)
+assert torch.equal(out, ids)
+model = torch.nn.Linear(8, 4).cuda()
+for p in model.parameters():
+    p.grad = torch.ones_like(p)
+g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+dist.all_reduce(g)
+assert float(g.sum()) == g.numel()
+assert all_reduce_gradients(model) == 0          # world size 1: nothing to reduce
+dist.barrier()
+dist.destroy_process_group()
+print('RCCL_OK', torch.cuda.nccl.version())
+"""
+    env = dict(os.environ, ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
