@@ -321,6 +321,9 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *                         problems in every workgroup, one after the other; 0 = the second half of the grid takes problem 2.
  * D3PM_TUNE_GEMM_PERSIST_SLOTS: resident workgroups of the persistent throughput schedule, a multiple of 8
  *                         (default 1024 = 4 per CU).
+ * D3PM_TUNE_GELU_TABLE:   1 = the bf16 GELU epilogue of the 192 x 256 big-tile and the latency GEMM reads rn_bf16(gelu(v)) from
+ *                         an 8.5 KiB LDS table filled on the device by the arithmetic path itself (bit-identical results);
+ *                         0 (default: the table measured slower, 86 vs 73 us on fc1) = always the arithmetic path.
  * D3PM_TUNE_ATTN_CROSS_RESIDENT: 1 (default) = the text + prompt cross-attention pair of a block (<= 64 and <= 256 keys) runs
  *                         with every K / V tile of both problems fetched into LDS at kernel entry (one wait, no per-tile
  *                         barrier, 256 queries per workgroup); 0 = the tile-by-tile kernel.  Same results.
@@ -334,7 +337,7 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *                         MFMA, 64 no barriers, 128 no LDS reads, 256 clock stamp for d3pm_debug_gemm_clock). */
 enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2,
        D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4, D3PM_TUNE_FUSED_FINAL_SAMPLE = 5,
-       D3PM_TUNE_ATTN_CROSS_RESIDENT = 6 };
+       D3PM_TUNE_ATTN_CROSS_RESIDENT = 6, D3PM_TUNE_GELU_TABLE = 7 };
 int d3pm_set_tuning(int knob, int value);
 
 /* Single-op entry of the fused final projection + posterior + draw (replaces `final` at ar_discrete.py:776 followed by

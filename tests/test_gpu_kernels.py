@@ -361,3 +361,23 @@ def test_cross_attention_pair_resident_kernel_equals_the_tile_by_tile_kernel(bui
     finally:
         _hip.set_attn_cross_resident(True)
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+
+
+def test_gelu_table_lookup_is_bit_identical_to_the_arithmetic_epilogue(built_lib):
+    """D3PM_TUNE_GELU_TABLE (opt-in): rn_bf16(gelu(v)) from the LDS table the device fills with the arithmetic path itself."""
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(2)
+    x = (torch.randn(1536, 512, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(2048, 512, generator=g) / math.sqrt(512)).to(torch.bfloat16).to(DEV)
+    b = torch.randn(2048, generator=g).to(torch.bfloat16).to(DEV)
+    outs = []
+    try:
+        for variant in (6, 4):
+            _hip.set_gemm_variant(variant)
+            for tab in (False, True):
+                _hip.set_gelu_table(tab)
+                outs.append(_hip.op_linear(x, w, b, act=1, family=_hip.FAMILY_MFMA).clone())
+    finally:
+        _hip.set_gemm_variant(0)
+        _hip.set_gelu_table(False)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])

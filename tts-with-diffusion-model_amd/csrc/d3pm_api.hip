@@ -30,6 +30,7 @@ void set_gemm_persist_slots(int v);
 void set_attn_pair_sequential(int v);
 void set_attn_qg(int v);
 void set_attn_cross_resident(int v);
+void set_gelu_table(int v);
 void set_big_gemm_mode(int v);
 bool final_sample_supported(int dtype, int n_classes, int d, const void* X, int ldx, const void* W);
 int final_sample(int dtype, const void* X, int ldx, const void* W, const void* bias, int d, const SampleArgs& a, hipStream_t s);
@@ -729,6 +730,7 @@ int d3pm_set_tuning(int knob, int value) {
   if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && value >= 0 && value <= 2) { set_attn_qg(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && (value == 0 || value == 1)) { set_attn_pair_sequential(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 9 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465)) { set_big_gemm_mode(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_GELU_TABLE && (value == 0 || value == 1)) { set_gelu_table(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_CROSS_RESIDENT && (value == 0 || value == 1)) { set_attn_cross_resident(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_FUSED_FINAL_SAMPLE && (value == 0 || value == 1)) { g_fused_final_sample = value; return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_PERSIST_SLOTS && value >= 8 && value <= 4096 && value % 8 == 0) { set_gemm_persist_slots(value); return D3PM_OK; }

@@ -329,7 +329,31 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128_persist(const T* __restr
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+__device__ uint16_t g_gelu_bf16[GELU_TAB_ENTRIES];
+__global__ void fill_gelu_table() {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= GELU_TAB_ENTRIES) return;
+  const uint32_t sign = i / (GELU_TAB_NE * 128), rem = i % (GELU_TAB_NE * 128);
+  const uint32_t bits = (sign << 15) | ((rem / 128 + GELU_TAB_E0) << 7) | (rem % 128);
+  const float v = __uint_as_float(bits << 16);
+  g_gelu_bf16[i] = static_cast<uint16_t>(__float_as_uint(rn<bf16>(gelu_erf(v))) >> 16);
+}
+
 }  // namespace
+
+// Device address of the bf16 GELU table (d3pm_mfma_tile.h), filled on first use on `s` (a static of the library: no
+// allocation; the fill kernel is idempotent, so a capture that happens to contain it replays harmlessly).
+const uint16_t* gelu_table_device(hipStream_t s) {
+  static const uint16_t* ptr = nullptr;
+  if (!ptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_gelu_bf16)) != hipSuccess) return nullptr;
+    fill_gelu_table<<<(GELU_TAB_ENTRIES + 255) / 256, 256, 0, s>>>();
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    ptr = static_cast<const uint16_t*>(p);
+  }
+  return ptr;
+}
 
 bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;

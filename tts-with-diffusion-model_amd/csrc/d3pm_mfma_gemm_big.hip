@@ -66,7 +66,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
                                                         const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                         const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                         int mask_period, int M, int N, int K, int n_tiles,
-                                                        int tiles_total) {
+                                                        int tiles_total, const uint16_t* __restrict__ gelu_tab_g) {
   constexpr int NW = WM * WN, TM = 96 * WM, TN = 64 * WN;   // 8 waves: one workgroup per CU; 4 waves: two
   constexpr int XD = TM / 8, WD = TN / 8;              // 1-KiB DMA pieces (8 rows x 128 B) per k-step and operand
   constexpr int XPW = (XD + NW - 1) / NW, WPW = WD / NW;   // pieces per wave
@@ -119,6 +119,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   const char* const fx_base = smem + wm * 96 * ROW_BYTES;
   const char* const fw_base = smem + X_BYTES + wn * 64 * ROW_BYTES;
 
+  // bf16 GELU epilogue: the lookup table rides behind the two stages (only where it fits: 192 x 256 tiles)
+  const uint16_t* gelu_tab = nullptr;
+  if constexpr ((EPI & EPI_GELU) != 0 && std::is_same<T, bf16>::value && 2 * STAGE + GELU_TAB_BYTES <= 160 * 1024 && NW == 8) {
+    if (gelu_tab_g) {
+      gelu_table_to_lds(gelu_tab_g, smem + 2 * STAGE, tid, NW * 64);
+      gelu_tab = reinterpret_cast<const uint16_t*>(smem + 2 * STAGE);     // the first k-step's barrier publishes it
+    }
+  }
   if constexpr (kPrioYoung) {      // the later-dispatched half of an 8-wave workgroup loses issue arbitration on its SIMD
     if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
   }
@@ -255,12 +263,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
     }
     if (kDrip && more) {      // keep the finished tile in registers: its stores go out inside the next tile's first k-steps
       epilogue_store<T, EPI, 4, 6, true, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
-                                               n0 + wn * 64, lane, pend);
+                                               n0 + wn * 64, lane, pend, gelu_tab);
       pend_y = Y + static_cast<size_t>(m0 + wm * 96 + (lane & 15)) * ldy + n0 + wn * 64 + epilogue_nq(lane);
       pending = true;
     } else {
       epilogue_store<T, EPI, 4, 6, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
-                                         n0 + wn * 64, lane);
+                                         n0 + wn * 64, lane, nullptr, gelu_tab);
     }
     if (!more) break;
     t = t_next;
@@ -288,6 +296,14 @@ static void big_geometry(int id, int& tm, int& tn, int& waves) {
   waves = id == 3 ? 4 : 8;
 }
 
+const uint16_t* gelu_table_device(hipStream_t s);
+// D3PM_TUNE_GELU_TABLE: bf16 GELU epilogues read an LDS table (d3pm_mfma_tile.h).  Off: measured SLOWER on MI355X -- fc1 + GELU at
+// M = 24576 with 192 x 256 tiles 86.4 us with the table vs 72.6 us with the polynomial (67.9 us for the shipped 192 x 128
+// geometry); 64 random 2-byte LDS reads per instruction cost more than the 17 vector instructions they replace
+static int g_gelu_table = 0;
+void set_gelu_table(int v) { g_gelu_table = v; }
+int gelu_table_enabled() { return g_gelu_table; }
+
 // 0 = not applicable, else the geometry id.  `want` (tuning knob): 0 auto, 1 / 2 / 3 forced.
 int big_linear_tile(int dtype, const LinearArgs& a, int want) {
   if (dtype != D3PM_F16 && dtype != D3PM_BF16) return 0;
@@ -312,7 +328,7 @@ int big_linear_tile(int dtype, const LinearArgs& a, int want) {
   if (want >= 1 && want <= 3) return fits(want, true) ? want : 0;
   // measured at the bench shapes (tests/ab_gemm.py, profiles/round2_*): 192 x 256 wins everywhere except under the GELU
   // epilogue, whose VALU work only overlaps with MFMAs when a second workgroup shares the CU (192 x 128, two per CU)
-  if (gelu && fits(3, false)) return 3;
+  if (gelu && !(dtype == D3PM_BF16 && g_gelu_table) && fits(3, false)) return 3;   // bf16: table lookup, cheap enough for one WG per CU
   if (fits(2, false)) return 2;
   if (fits(3, false)) return 3;
   return fits(1, false) ? 1 : 0;
@@ -327,6 +343,11 @@ int read_big_gemm_stamp(unsigned long long* out) {
 
 template <typename U, int E, int WM, int WN, int MD>
 static int big_launch(const LinearArgs& a, int n_tiles, int tiles_total, dim3 grid, size_t lds, hipStream_t s) {
+  const uint16_t* tab = nullptr;
+  if ((E & EPI_GELU) && std::is_same<U, bf16>::value && WM * WN == 8 && lds + GELU_TAB_BYTES <= 160 * 1024 && g_gelu_table) {
+    tab = gelu_table_device(s);
+    if (tab) lds += GELU_TAB_BYTES;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_big<U, E, WM, WN, MD>),
@@ -336,7 +357,7 @@ static int big_launch(const LinearArgs& a, int n_tiles, int tiles_total, dim3 gr
   gemm_mfma_big<U, E, WM, WN, MD><<<grid, dim3(WM * WN * 64), lds, s>>>(
       static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
       static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles,
-      tiles_total);
+      tiles_total, tab);
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;
 }

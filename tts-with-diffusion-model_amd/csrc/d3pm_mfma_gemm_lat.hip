@@ -36,11 +36,19 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                             const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                             const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                                            int mask_period, int M, int N, int K, int n_tiles) {
+                                                            int mask_period, int M, int N, int K, int n_tiles,
+                                                            const uint16_t* __restrict__ gelu_tab_g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  const uint16_t* gelu_tab = nullptr;
+  if constexpr ((EPI & EPI_GELU) != 0 && std::is_same<T, bf16>::value) {
+    if (gelu_tab_g) {                       // bf16 GELU by table lookup (d3pm_mfma_tile.h); published by the first barrier
+      gelu_table_to_lds(gelu_tab_g, smem + 2 * BUF_BYTES, tid, 256);
+      gelu_tab = reinterpret_cast<const uint16_t*>(smem + 2 * BUF_BYTES);
+    }
+  }
   const int bid = xcd_remap_lat(blockIdx.x, gridDim.x);
   const int m0 = (bid / n_tiles) * LT, n0 = (bid % n_tiles) * LT;
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
@@ -109,7 +117,8 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
       issue_round(r + 2, buf);
     }
   }
-  epilogue_store<T, EPI, 2, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 32, n0 + wn * 32, lane);
+  epilogue_store<T, EPI, 2, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 32, n0 + wn * 32, lane, nullptr,
+                               gelu_tab);
 }
 
 inline bool aligned16l(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
@@ -129,7 +138,12 @@ bool panel64_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
+const uint16_t* gelu_table_device(hipStream_t s);
+int gelu_table_enabled();
+
 int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s) {
+  const uint16_t* tab = (a.act == ACT_GELU && dtype == D3PM_BF16 && gelu_table_enabled()) ? gelu_table_device(s) : nullptr;
+  const size_t lds = 2 * BUF_BYTES + (tab ? GELU_TAB_BYTES : 0);
   const int n_tiles = (a.N + LT - 1) / LT, m_tiles = (a.M + LT - 1) / LT;
   const dim3 grid(static_cast<unsigned>(n_tiles * m_tiles)), block(256);
   const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
@@ -138,12 +152,12 @@ int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s) {
     static bool attr_set = false;                                                                                       \
     if (!attr_set) {                                                                                                    \
       D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_panel64<U, E>),                       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES));                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + GELU_TAB_BYTES));  \
       attr_set = true;                                                                                                  \
     }                                                                                                                   \
-    gemm_mfma_panel64<U, E><<<grid, block, 2 * BUF_BYTES, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), \
+    gemm_mfma_panel64<U, E><<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), \
         static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy, static_cast<const U*>(a.R1),                       \
-        static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles);                         \
+        static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles, tab);                    \
     return D3PM_OK;                                                                                                     \
   } while (0)
   auto go = [&](auto* tag) -> int {

@@ -2,6 +2,8 @@
 // fragment types, the swizzled 128-byte-row LDS image, the direct-to-LDS DMA helpers and the epilogue that turns
 // fp32 accumulators into bias / activation / residual / mask -ed 16-byte stores with the eager rounding points.
 #pragma once
+#include <type_traits>
+
 #include "d3pm_kernels.h"
 
 namespace d3pm {
@@ -48,6 +50,27 @@ __device__ __forceinline__ float erf_fit(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fit(v * 0.70710678118654752f)); }
 
+// GELU of a bf16 value is a function of 16 bits: for 2^-14 <= |v| < 8 (bf16 exponent fields 113 .. 129: every value an
+// activation takes in practice) the result rn_bf16(gelu_erf(v)) is read from an 8.5 KiB table in LDS -- ~8 vector
+// instructions and one ds_read_u16 instead of the ~25 of the polynomial (the GELU epilogue is VALU-bound: 96 elements per
+// lane and tile).  The table is filled on the device by gelu_erf itself (gelu_table_device, d3pm_mfma_gemm.hip), so the
+// lookup returns bit for bit what the arithmetic path returns; values outside the range take the arithmetic path.
+constexpr int GELU_TAB_E0 = 113, GELU_TAB_NE = 17;
+constexpr int GELU_TAB_ENTRIES = 2 * GELU_TAB_NE * 128;       // [sign][exponent][mantissa]
+constexpr int GELU_TAB_BYTES = GELU_TAB_ENTRIES * 2;          // 8704
+__device__ __forceinline__ float gelu_bf16_lookup(float v, const uint16_t* tab) {
+  const uint32_t b = __float_as_uint(v) >> 16;                // v is a bf16 value held in a float
+  const uint32_t e = ((b >> 7) & 0xFFu) - GELU_TAB_E0;
+  if (e < static_cast<uint32_t>(GELU_TAB_NE))
+    return __uint_as_float(static_cast<uint32_t>(tab[e * 128u + (b & 127u) + (b >> 15) * (GELU_TAB_NE * 128u)]) << 16);
+  return rn<bf16>(gelu_erf(v));
+}
+// workgroup-wide copy of the table into LDS (caller synchronises before the first lookup)
+__device__ __forceinline__ void gelu_table_to_lds(const uint16_t* __restrict__ gtab, char* lds, int tid, int nthreads) {
+  for (int i = tid; i < GELU_TAB_BYTES / 16; i += nthreads)
+    reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(gtab)[i];
+}
+
 // Epilogue.  The MFMA leaves D[n = nt*16 + (lane>>4)*4 + r][m = mt*16 + (lane&15)] in a lane: 4 consecutive
 // columns of one row per (nt, mt), i.e. 8-byte stores that touch 32 contiguous bytes per row and instruction.
 // v_permlane16_swap between the accumulators of column blocks nt and nt+1 (odd 16-lane rows of the first operand
@@ -86,7 +109,7 @@ template <typename T, int EPI, int NT = 4, int MT = 4, bool kInteriorOnly = fals
 __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* __restrict__ bias, T* Y, int ldy,
                                                const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                int mask_period, int M, int N, int mw0, int nw0, int lane,
-                                               uintx4* packed = nullptr) {
+                                               uintx4* packed = nullptr, const uint16_t* gelu_tab = nullptr) {
   static_assert(!kPack || kInteriorOnly, "packing to registers is for whole tiles");
   static_assert(NT % 2 == 0, "column blocks are regrouped in pairs");
   constexpr bool kGelu = EPI & EPI_GELU, kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
@@ -130,7 +153,10 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       v[r] = rn<T>(acc[2 * np + (r >> 2)][mt][r & 3] + bv[2 * np + (r >> 2)][r & 3]);
-      if (kGelu) v[r] = rn<T>(gelu_erf(v[r]));
+      if constexpr (kGelu) {
+        if constexpr (std::is_same<T, bf16>::value) v[r] = gelu_tab ? gelu_bf16_lookup(v[r], gelu_tab) : rn<T>(gelu_erf(v[r]));
+        else v[r] = rn<T>(gelu_erf(v[r]));
+      }
       if (EPI & EPI_RELU) v[r] = fmaxf(v[r], 0.f);
       if (EPI & EPI_SILU) v[r] = rn<T>(v[r] / (1.0f + expf(-v[r])));
     }

@@ -658,6 +658,10 @@ def set_attn_pair_sequential(v: bool):
     check(lib().d3pm_set_tuning(3, 1 if v else 0), "d3pm_set_tuning")
 
 
+def set_gelu_table(v: bool):
+    check(lib().d3pm_set_tuning(7, 1 if v else 0), "d3pm_set_tuning")
+
+
 def set_attn_cross_resident(v: bool):
     check(lib().d3pm_set_tuning(6, 1 if v else 0), "d3pm_set_tuning")
 
