@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket GEMM launches with HIP events (roofline.achieved is then 0): measures what the "
                          "event pairs cost the timed region")
+    ap.add_argument("--tune", default="", help="A/B ONLY: comma-separated knob=value pairs for d3pm_set_tuning "
+                    "(include/d3pm_hip.h), e.g. 8=0; the JSON line records them and is not the headline configuration")
     ap.add_argument("--profile-iters", type=int, default=0,
                     help="PROFILING ONLY: run this many diffusion iterations instead of all 99 (the JSON line is then "
                          "marked invalid_for_headline)")
@@ -219,6 +221,9 @@ def main():
     import __graft_entry__ as g
     g.build()
     from vall_e.vall_e import AR, _hip, dp, synth
+    for kv in filter(None, args.tune.split(",")):
+        knob, value = (int(v) for v in kv.split("="))
+        _hip.check(_hip.lib().d3pm_set_tuning(knob, value), "d3pm_set_tuning")
 
     cfg = {"libritts": synth.D3PMConfig.libritts, "native": synth.D3PMConfig.native,
            "vctk": synth.D3PMConfig.vctk_long_prompt}[args.config]()
@@ -279,6 +284,8 @@ def main():
                    "utterances_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
                    "streams_per_gpu": args.streams},
     }
+    if args.tune:
+        result["tuning_overrides"] = args.tune
     if args.profile_iters:
         result["invalid_for_headline"] = f"profiling run: {iters} of {cfg.timesteps - 1} diffusion iterations"
     if rank == 0:

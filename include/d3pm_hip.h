@@ -301,6 +301,21 @@ int d3pm_op_attention(int dtype, int family, const void *Q, int ldq, const void 
                       void *O, int ldo, int B, int Tq, int S, int H, int hd, float scale, void *stream);
 int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const void *b, const void *film,
                       int M, int d, float eps, void *stream);
+/* Row-panel projection (d_model = 512): a Linear whose output is added to the residual stream, together with the LayerNorm(s)
+ * the block applies to the new rows next, in ONE launch -- a workgroup owns whole rows (96 x 512 tiles), so the row moments
+ * are reduced on chip.  Three forms, each bit-identical to the launches it replaces (d3pm_op_linear, then d3pm_op_layernorm):
+ *   self-attention out-projection  (ar_discrete.py:132-136): X2 = film = row_mask = NULL, both LayerNorms:
+ *       Y = rn(R1 + rn(X W^T + bias)),  ln_y = norm2(Y),  ln2_y = norm22(Y);
+ *   both cross-attention out-projections (:138-143, the SAME weights): X2 given, film given, ln2_* = row_mask = NULL:
+ *       Y = rn(rn(R1 + rn(X W^T + bias)) + rn(X2 W^T + bias)),  ln_y = FiLM(norm3(Y))  (:145-156);
+ *   MLP down-projection (:159-161): row_mask given, X2 = film = ln2_* = NULL:
+ *       Y = rn(R1 + rn(X W^T + bias)) * mask[row % mask_period],  ln_y = norm1 of the NEXT block (:131).
+ * X (and X2) [M][ldx], W [512][K], Y / R1 / ln_y / ln2_y [M][512] (Y may alias R1), M a multiple of 96, K a multiple of 128.
+ * D3PM_E_SHAPE for any other combination. */
+int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, const void *W, const void *bias, void *Y,
+                            const void *R1, const uint8_t *row_mask, int mask_period, int M, int K, const void *ln_w,
+                            const void *ln_b, void *ln_y, const void *ln2_w, const void *ln2_b, void *ln2_y,
+                            const void *film, float eps, void *stream);
 
 /* Tuning knobs (process-wide; defaults are what bench.py measures).
  * D3PM_TUNE_GEMM_VARIANT: 0 = auto (default): big-tile persistent schedule (192 x 256 or 96 x 512 tiles, eight waves,
@@ -331,13 +346,17 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *                         kernel and the logits never reach HBM (16-bit model, d_model a multiple of 32, MFMA family);
  *                         0 (default: measured faster) = the two-launch form (final GEMM, then d3pm_posterior_sample's
  *                         kernel).  Same ids either way.
+ * D3PM_TUNE_ROW_PANEL:    bit mask of the block's projections that run as row-panel launches (d3pm_op_linear_rowpanel) when
+ *                         d_model = 512, the dtype is 16-bit and batch * canvas is a multiple of 96: 1 = self-attention
+ *                         out-projection + norm2 | norm22, 2 = both cross-attention out-projections + norm3 / FiLM, 4 = fc2 +
+ *                         the next block's norm1.  Default 3 (fc2 measured slower fused).  Same results as the separate launches.
  * D3PM_TUNE_GEMM_BIG_MODE: schedule of the big-tile GEMM: 1 (default) / 0 = hand-placed / compiler-placed fragment reads (same
  *                         results);
  *                         >= 16 = timing-only ablation builds for tests/ab_gemm.py (WRONG results; bits: 16 no DMA, 32 no
  *                         MFMA, 64 no barriers, 128 no LDS reads, 256 clock stamp for d3pm_debug_gemm_clock). */
 enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2,
        D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4, D3PM_TUNE_FUSED_FINAL_SAMPLE = 5,
-       D3PM_TUNE_ATTN_CROSS_RESIDENT = 6, D3PM_TUNE_GELU_TABLE = 7 };
+       D3PM_TUNE_ATTN_CROSS_RESIDENT = 6, D3PM_TUNE_GELU_TABLE = 7, D3PM_TUNE_ROW_PANEL = 8 };
 int d3pm_set_tuning(int knob, int value);
 
 /* Single-op entry of the fused final projection + posterior + draw (replaces `final` at ar_discrete.py:776 followed by

@@ -381,3 +381,68 @@ def test_gelu_table_lookup_is_bit_identical_to_the_arithmetic_epilogue(built_lib
         _hip.set_gemm_variant(0)
         _hip.set_gelu_table(False)
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("form,M,K", [("self_out", 96 * 300, 512), ("cross_out", 96 * 300, 512), ("mlp_down", 96 * 258, 2048),
+                                      ("self_out", 96, 256), ("cross_out", 192, 512), ("mlp_down", 96 * 3, 256)])
+def test_row_panel_projection_equals_linear_then_layernorm(built_lib, dtype, form, M, K):
+    """d3pm_op_linear_rowpanel (projection onto the residual stream + the LayerNorms of the new rows, one launch) against the
+    launches it replaces inside the block -- d3pm_op_linear, then d3pm_op_layernorm: same bits in x and in every LayerNorm
+    output, for one round of tiles, more tiles than CUs (persistent walk) and a handful of tiles."""
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dtype).to(DEV)
+    x, x2, r1 = mk(M, K), mk(M, K), mk(M, 512, sc=2.0)
+    w, b = mk(512, K, sc=1.0 / math.sqrt(K)), mk(512, sc=0.3)
+    lw, lb, lw2, lb2 = mk(512, sc=0.5) + 1, mk(512, sc=0.2), mk(512, sc=0.5) + 1, mk(512, sc=0.2)
+    film = mk(1024, sc=0.3)
+    period = 96 * 3 if M % (96 * 3) == 0 else M
+    mask = (torch.rand(period, generator=g) < 0.9).to(torch.uint8).to(DEV)
+    if form == "self_out":
+        y, l1, l2 = _hip.op_linear_rowpanel(x, w, b, r1, lw, lb, ln2_w=lw2, ln2_b=lb2)
+        y_ref = _hip.op_linear(x, w, b, r1=r1, family=_hip.FAMILY_MFMA)
+        refs = [_hip.op_layernorm(y_ref, lw, lb), _hip.op_layernorm(y_ref, lw2, lb2)]
+        outs = [l1, l2]
+    elif form == "cross_out":
+        y, l1, l2 = _hip.op_linear_rowpanel(x, w, b, r1, lw, lb, x2=x2, film=film)
+        h = _hip.op_linear(x, w, b, family=_hip.FAMILY_MFMA)
+        y_ref = _hip.op_linear(x2, w, b, r1=r1, r2=h, family=_hip.FAMILY_MFMA)
+        refs, outs = [_hip.op_layernorm(y_ref, lw, lb, film=film)], [l1]
+        assert l2 is None
+    else:
+        y, l1, l2 = _hip.op_linear_rowpanel(x, w, b, r1, lw, lb, row_mask=mask)
+        y_ref = _hip.op_linear(x, w, b, r1=r1, row_mask=mask, mask_period=period, family=_hip.FAMILY_MFMA)
+        refs, outs = [_hip.op_layernorm(y_ref, lw, lb)], [l1]
+    assert torch.equal(y, y_ref), f"{form}: residual stream differs in {(y != y_ref).sum().item()} elements"
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert torch.equal(o, r), f"{form}: LayerNorm output {i} differs in {(o != r).sum().item()} elements"
+
+
+def test_row_panel_rejects_other_combinations(built_lib):
+    from vall_e.vall_e import _hip
+    z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError):      # 100 rows: not whole 96-row tiles
+        _hip.op_linear_rowpanel(z(100, 512), z(512, 512), z(512), z(100, 512), z(512), z(512), ln2_w=z(512), ln2_b=z(512))
+    with pytest.raises(RuntimeError):      # a single LayerNorm without mask / FiLM / second operand is not one of the three forms
+        _hip.op_linear_rowpanel(z(96, 512), z(512, 512), z(512), z(96, 512), z(512), z(512))
+
+
+def test_sample_loop_is_the_same_with_and_without_row_panel_launches(built_lib):
+    """D3PM_TUNE_ROW_PANEL inside the loop: ids after a few reverse steps with every fused form on and off (bench shape rows:
+    32 x 768 = 256 tiles of 96 rows)."""
+    from vall_e.vall_e import AR, _hip, synth
+    cfg = synth.D3PMConfig.libritts()
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0))
+    m = m.to(torch.bfloat16).to(DEV)
+    texts, proms = synth.make_inputs(cfg, 32, 1)
+    outs = []
+    try:
+        for maskbits in (0, 7, 1, 2, 4):
+            _hip.set_row_panel(maskbits)
+            outs.append(m.generate_audio(texts, proms, steps=3, seed=4).clone())
+    finally:
+        _hip.set_row_panel(3)
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)

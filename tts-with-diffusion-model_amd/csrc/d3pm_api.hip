@@ -39,6 +39,10 @@ int final_sample(int dtype, const void* X, int ldx, const void* W, const void* b
 // lane: Philox, three logf, expf, a division, the fp16 rounding points) and wants 8 waves per SIMD, the fused kernel's 66 KB
 // logits image allows 2
 static int g_fused_final_sample = 0;
+// D3PM_TUNE_ROW_PANEL: projections onto the residual stream normalise their rows in the epilogue (d3pm_mfma_gemm_big.hip)
+// measured on the bench workload (tools/ab_tune.sh, profiles/round2_c_ab_row_panel.txt): 1 | 2 gains 0.9 %; fc2 (4) loses -- its
+// K = 2048 product runs 30 us slower on 96 x 512 tiles than on 192 x 256, more than the norm1 launch it saves
+static int g_row_panel = 3;
 int read_big_gemm_stamp(unsigned long long* out);
 
 // ---- profiling hooks (bench.py roofline object) ----------------------------------------------
@@ -84,6 +88,14 @@ static int run_linear(int dtype, const LinearArgs& a, uint32_t flags, hipStream_
                     static_cast<double>(a.M) * a.N * (1 + (a.R1 ? 1 : 0) + (a.R2 ? 1 : 0))));
   if (!(flags & D3PM_FLAG_FORCE_GENERIC) && mfma_linear_supported(dtype, a)) return mfma_linear(dtype, a, s);
   return generic_linear(dtype, a, s);
+}
+// projection onto the residual stream + the LayerNorm(s) of the new rows, one launch (d3pm_mfma_gemm_big.hip)
+static int run_row_panel(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s) {
+  const size_t es = dtype_size(dtype);
+  const double prods = f.X2 ? 2.0 : 1.0, mn = static_cast<double>(a.M) * a.N;
+  ProfScope p(D3PM_K_GEMM, s, prods * 2.0 * a.M * a.N * a.K,
+              es * (prods * a.M * a.K + static_cast<double>(a.N) * a.K + mn * (3.0 + (f.lny2 ? 1.0 : 0.0))));
+  return row_panel_linear(dtype, a, f, s);
 }
 static int run_attention(int dtype, const AttnArgs& a, uint32_t flags, hipStream_t s) {
   ProfScope p(D3PM_K_ATTN, s, 4.0 * a.B * a.H * a.Tq * static_cast<double>(a.S + a.S2) * a.hd,
@@ -175,6 +187,14 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
   e.M = n; e.d = d; e.n_classes = sh.n_classes;
   D3PM_TRY(embed_tokens(dt, e, s));
 
+  // row-panel launches (D3PM_TUNE_ROW_PANEL): a projection that lands on the residual stream also writes the LayerNorm(s) the
+  // block applies to the new rows next -- same bits, one launch and one pass over x less each
+  // (one 96-row tile per workgroup: only when the tiles fill >= 85 % of whole rounds over the 256 CUs, as for the other big tiles)
+  const long long rp_tiles = n / 96, rp_rounds = (rp_tiles + 255) / 256;
+  const bool rp_fills = n % 96 == 0 && rp_tiles * 5 >= 256 * 4 && rp_tiles * 100 >= rp_rounds * 256 * 85;
+  const int panel = (!use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && rp_fills && (dt == D3PM_F16 || dt == D3PM_BF16)) ? g_row_panel : 0;
+  bool norm1_done = false;      // the previous block's fc2 launch already wrote norm1(x) of this block to ws.h
+
   for (int l = 0; l < layers; ++l) {
     const d3pm_block_weights& b = w.blocks[l];
     // ---- self-attention ----
@@ -189,9 +209,10 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].attn_in_w8), f8[l].attn_in_scale, b.attn_in_b, ws.qkv,
                           3 * d, n, 3 * d, d, ACT_NONE, s));
     } else {
-      D3PM_TRY(run_layernorm(dt, ln, flags, s));
+      if (!norm1_done) D3PM_TRY(run_layernorm(dt, ln, flags, s));
       D3PM_TRY(run_linear(dt, g, flags, s));
     }
+    norm1_done = false;
     AttnArgs a;
     a.Q = ws.qkv; a.ldq = 3 * d; a.K = at(ws.qkv, d, es); a.V = at(ws.qkv, 2 * d, es); a.ldkv = 3 * d;
     a.O = ws.att; a.ldo = d; a.B = batch; a.Tq = T; a.S = T; a.H = H; a.hd = hd; a.scale = scale;
@@ -199,11 +220,15 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     g = LinearArgs();
     g.X = ws.att; g.ldx = d; g.W = b.attn_out_w; g.bias = b.attn_out_b; g.Y = ws.x; g.ldy = d;
     g.R1 = ws.x; g.ldr = d; g.M = n; g.N = d; g.K = d;
-    D3PM_TRY(run_linear(dt, g, flags, s));
     // ---- cross-attention: text keys with LN2 queries, prompt keys with LN22 queries, SAME weights ----
     ln = LayerNormArgs();
     ln.X = ws.x; ln.Y = ws.h; ln.w = b.norm2_w; ln.b = b.norm2_b; ln.Y2 = ws.h2; ln.w2 = b.norm22_w; ln.b2 = b.norm22_b;
     ln.M = n; ln.d = d; ln.eps = 1e-6f;
+    RowPanelFuse rp;
+    rp.lnw = ln.w; rp.lnb = ln.b; rp.lny = ln.Y; rp.lnw2 = ln.w2; rp.lnb2 = ln.b2; rp.lny2 = ln.Y2; rp.eps = ln.eps;
+    const bool norm2_fused = (panel & 1) && row_panel_supported(dt, g, rp);
+    if (norm2_fused) D3PM_TRY(run_row_panel(dt, g, rp, s));
+    else D3PM_TRY(run_linear(dt, g, flags, s));
     char* q_text = ws.qkv;
     char* q_prom = at(ws.qkv, static_cast<size_t>(n) * d, es);
     if (use8) {
@@ -214,14 +239,14 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].cross_in_w8), f8[l].cross_in_scale, b.cross_in_b,
                           q_text, d, 2 * n, d, d, ACT_NONE, s));
     } else if (ws.h2 == at(ws.h, static_cast<size_t>(n) * d, es)) {
-      D3PM_TRY(run_layernorm(dt, ln, flags, s));
+      if (!norm2_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
       // both query projections share cross_attn's q rows: LN2|LN22 outputs and q_text|q_prompt are adjacent in
       // the workspace, so the pair is ONE [2n, d] x [d, d] GEMM (twice the workgroups of either alone)
       g = LinearArgs();
       g.X = ws.h; g.ldx = d; g.W = b.cross_in_w; g.bias = b.cross_in_b; g.Y = q_text; g.ldy = d; g.M = 2 * n; g.N = d; g.K = d;
       D3PM_TRY(run_linear(dt, g, flags, s));
     } else {
-      D3PM_TRY(run_layernorm(dt, ln, flags, s));
+      if (!norm2_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
       for (int which = 0; which < 2; ++which) {
         g = LinearArgs();
         g.X = which ? ws.h2 : ws.h; g.ldx = d; g.W = b.cross_in_w; g.bias = b.cross_in_b;
@@ -238,18 +263,28 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       a.Q2 = q_prom; a.K2 = kvp; a.V2 = at(kvp, d, es); a.O2 = ws.att2; a.S2 = sh.s_prompt;
       D3PM_TRY(run_attention(dt, a, flags, s));
     }
-    // o_text -> h (free now); x = (x + o_text) + o_prompt, rounded at each add like the eager sum
-    g = LinearArgs();
-    g.X = ws.att; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.h; g.ldy = d; g.M = n; g.N = d; g.K = d;
-    D3PM_TRY(run_linear(dt, g, flags, s));
-    g = LinearArgs();
-    g.X = ws.att2; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.x; g.ldy = d;
-    g.R1 = ws.x; g.R2 = ws.h; g.ldr = d; g.M = n; g.N = d; g.K = d;
-    D3PM_TRY(run_linear(dt, g, flags, s));
-    // ---- FiLM-modulated MLP ----
+    // ---- both out-projections, then the FiLM-modulated MLP ----
     ln = LayerNormArgs();
     ln.X = ws.x; ln.Y = ws.h; ln.w = b.norm3_w; ln.b = b.norm3_b; ln.M = n; ln.d = d; ln.eps = 1e-6f;
     ln.film = at(film, (static_cast<size_t>(t) * sh.n_layers + l) * 2 * d, es);
+    g = LinearArgs();
+    g.X = ws.att; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
+    g.M = n; g.N = d; g.K = d;
+    rp = RowPanelFuse();
+    rp.X2 = ws.att2; rp.lnw = ln.w; rp.lnb = ln.b; rp.lny = ln.Y; rp.film = ln.film; rp.eps = ln.eps;
+    const bool norm3_fused = (panel & 2) && row_panel_supported(dt, g, rp);
+    if (norm3_fused) {
+      D3PM_TRY(run_row_panel(dt, g, rp, s));
+    } else {
+      // o_text -> h (free now); x = (x + o_text) + o_prompt, rounded at each add like the eager sum
+      g = LinearArgs();
+      g.X = ws.att; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.h; g.ldy = d; g.M = n; g.N = d; g.K = d;
+      D3PM_TRY(run_linear(dt, g, flags, s));
+      g = LinearArgs();
+      g.X = ws.att2; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.x; g.ldy = d;
+      g.R1 = ws.x; g.R2 = ws.h; g.ldr = d; g.M = n; g.N = d; g.K = d;
+      D3PM_TRY(run_linear(dt, g, flags, s));
+    }
     g = LinearArgs();
     g.X = ws.h; g.ldx = d; g.W = b.fc1_w; g.bias = b.fc1_b; g.Y = ws.mlp; g.ldy = 4 * d; g.M = n; g.N = 4 * d; g.K = d;
     g.act = ACT_GELU;
@@ -259,13 +294,20 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].fc1_w8), f8[l].fc1_scale, b.fc1_b, ws.mlp, 4 * d, n,
                           4 * d, d, ACT_GELU, s));
     } else {
-      D3PM_TRY(run_layernorm(dt, ln, flags, s));
+      if (!norm3_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
       D3PM_TRY(run_linear(dt, g, flags, s));
     }
     g = LinearArgs();
     g.X = ws.mlp; g.ldx = 4 * d; g.W = b.fc2_w; g.bias = b.fc2_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
     g.row_mask = frame_mask; g.mask_period = T; g.M = n; g.N = d; g.K = 4 * d;
-    D3PM_TRY(run_linear(dt, g, flags, s));
+    rp = RowPanelFuse();
+    if (l + 1 < layers) { rp.lnw = w.blocks[l + 1].norm1_w; rp.lnb = w.blocks[l + 1].norm1_b; rp.lny = ws.h; rp.eps = 1e-6f; }
+    if ((panel & 4) && l + 1 < layers && row_panel_supported(dt, g, rp)) {
+      D3PM_TRY(run_row_panel(dt, g, rp, s));
+      norm1_done = true;
+    } else {
+      D3PM_TRY(run_linear(dt, g, flags, s));
+    }
   }
   return D3PM_OK;
 }
@@ -700,6 +742,21 @@ int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const vo
   return run_layernorm(dtype, ln, 0, static_cast<hipStream_t>(stream));
 }
 
+int d3pm_op_linear_rowpanel(int dtype, const void* X, const void* X2, int ldx, const void* W, const void* bias, void* Y, const void* R1,
+                            const uint8_t* row_mask, int mask_period, int M, int K, const void* ln_w, const void* ln_b, void* ln_y,
+                            const void* ln2_w, const void* ln2_b, void* ln2_y, const void* film, float eps, void* stream) {
+  D3PM_REQUIRE(X && W && bias && Y && R1 && ln_w && ln_b && ln_y && M > 0 && K > 0, D3PM_E_ARG, "d3pm_op_linear_rowpanel: bad arguments");
+  LinearArgs g;
+  g.X = X; g.ldx = ldx; g.W = W; g.bias = bias; g.Y = Y; g.ldy = 512; g.R1 = R1; g.ldr = 512; g.row_mask = row_mask;
+  g.mask_period = mask_period > 0 ? mask_period : 1; g.M = M; g.N = 512; g.K = K;
+  RowPanelFuse f;
+  f.X2 = X2; f.lnw = ln_w; f.lnb = ln_b; f.lny = ln_y; f.lnw2 = ln2_w; f.lnb2 = ln2_b; f.lny2 = ln2_y; f.film = film; f.eps = eps;
+  D3PM_REQUIRE(row_panel_supported(dtype, g, f), D3PM_E_SHAPE,
+               "d3pm_op_linear_rowpanel: needs a 16-bit dtype, M a multiple of 96, K a multiple of 128 (>= 256), 16-byte aligned "
+               "operands and one of the three fused forms (include/d3pm_hip.h)");
+  return row_panel_linear(dtype, g, f, static_cast<hipStream_t>(stream));
+}
+
 int d3pm_op_final_sample(const d3pm_shape* sh, const d3pm_weights* w, int batch, const void* hidden, const int32_t* x_t,
                          int32_t* x_next, int t, const d3pm_schedule* sched, uint64_t seed, uint32_t utt0, uint32_t flags,
                          void* stream) {
@@ -733,6 +790,7 @@ int d3pm_set_tuning(int knob, int value) {
   if (knob == D3PM_TUNE_GELU_TABLE && (value == 0 || value == 1)) { set_gelu_table(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_CROSS_RESIDENT && (value == 0 || value == 1)) { set_attn_cross_resident(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_FUSED_FINAL_SAMPLE && (value == 0 || value == 1)) { g_fused_final_sample = value; return D3PM_OK; }
+  if (knob == D3PM_TUNE_ROW_PANEL && value >= 0 && value <= 7) { g_row_panel = value; return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_PERSIST_SLOTS && value >= 8 && value <= 4096 && value % 8 == 0) { set_gemm_persist_slots(value); return D3PM_OK; }
   set_error("d3pm_set_tuning: unknown knob %d / value %d", knob, value);
   return D3PM_E_ARG;

@@ -27,6 +27,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
   return v;
 }
+// the same sum with the butterfly walked from lane distance 1 up to 32.  The vectorised LayerNorms use this order: lane L
+// holds the 8-element chunk L of a 512-wide row, and the GEMM epilogue that normalises a finished row in place
+// (d3pm_mfma_gemm_big.hip, row-panel kernel) holds chunk 8 wave + 4 np + 2 (lane bit 4) + (lane bit 5) -- low chunk bits
+// inside a wave, high bits across waves -- so walking low to high lets it reproduce this tree exactly: same bits out.
+__device__ __forceinline__ float wave_sum_up(float v) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));

@@ -29,13 +29,13 @@ __global__ __launch_bounds__(256) void layernorm_vec(const T* __restrict__ x, T*
 #pragma unroll
     for (int i = 0; i < 8; ++i) { v[c][i] = static_cast<float>(raw.v[i]); s += v[c][i]; }
   }
-  const float mean = wave_sum(s) / static_cast<float>(d);
+  const float mean = wave_sum_up(s) / static_cast<float>(d);
   float q = 0.f;
 #pragma unroll
   for (int c = 0; c < CH; ++c)
 #pragma unroll
     for (int i = 0; i < 8; ++i) { float t = v[c][i] - mean; q += t * t; }
-  const float rstd = rsqrtf(wave_sum(q) / static_cast<float>(d) + eps);
+  const float rstd = rsqrtf(wave_sum_up(q) / static_cast<float>(d) + eps);
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int col = (c * 64 + lane) * 8;

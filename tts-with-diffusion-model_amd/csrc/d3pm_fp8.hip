@@ -88,11 +88,11 @@ __global__ __launch_bounds__(256) void layernorm_fp8_rows(const T* __restrict__ 
   float v[8], s = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) { v[i] = static_cast<float>(raw.v[i]); s += v[i]; }
-  const float mean = wave_sum(s) / static_cast<float>(d);
+  const float mean = wave_sum_up(s) / static_cast<float>(d);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) { const float t = v[i] - mean; q += t * t; }
-  const float rstd = rsqrtf(wave_sum(q) / static_cast<float>(d) + eps);
+  const float rstd = rsqrtf(wave_sum_up(q) / static_cast<float>(d) + eps);
   const int col = lane * 8;
   const Vec8<T> wv = *reinterpret_cast<const Vec8<T>*>(w + col), bv = *reinterpret_cast<const Vec8<T>*>(b + col);
   float o[8];

@@ -52,6 +52,15 @@ struct LayerNormArgs {
   int M = 0, d = 0; float eps = 1e-6f;
 };
 
+// what the row-panel projection (d3pm_mfma_gemm_big.hip) does to the rows it has just finished: N = d_model = 512
+struct RowPanelFuse {
+  const void* X2 = nullptr;                                  // second operand through the same weights (dual out-projection)
+  const void* lnw = nullptr; const void* lnb = nullptr; void* lny = nullptr;        // LayerNorm of the new rows
+  const void* lnw2 = nullptr; const void* lnb2 = nullptr; void* lny2 = nullptr;     // a second LayerNorm of the same rows
+  const void* film = nullptr;                                // FiLM (scale | shift, 2 x 512) on the first
+  float eps = 1e-6f;
+};
+
 struct EmbedArgs {
   const int32_t* tokens = nullptr; const uint8_t* frame_mask = nullptr; int canvas = 0;
   const void* table = nullptr; void* Y = nullptr; int M = 0, d = 0, n_classes = 0;
@@ -101,6 +110,8 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a);
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s);
 bool mfma_attention_supported(int dtype, const AttnArgs& a);
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s);
+bool row_panel_supported(int dtype, const LinearArgs& a, const RowPanelFuse& f);
+int row_panel_linear(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s);
 bool fast_layernorm_supported(int dtype, const LayerNormArgs& a);
 int fast_layernorm(int dtype, const LayerNormArgs& a, hipStream_t s);
 

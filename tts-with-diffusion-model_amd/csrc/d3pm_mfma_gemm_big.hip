@@ -61,12 +61,26 @@ __device__ __forceinline__ void glds16_m0(const void* sbase, uint32_t voff, uint
 // take their operands from registers (no LDS reads)
 __device__ unsigned long long g_big_stamp[4];   // MODE bit 8: {shader clocks, 100 MHz ticks} of block 0 (clock under load)
 
-template <typename T, int EPI, int WM, int WN, int MODE>
+// Row-panel fusion (FUSE != 0; 96 x 512 tiles, d_model = 512 only: a workgroup then owns whole rows of the residual stream):
+//   bit 0  a SECOND product with the same weights runs through the same tile before the epilogue -- the text and prompt
+//          cross-attention outputs both go through cross_attn.out_proj (ar_discrete.py:138,142): h = rn(X W^T + b) stays
+//          packed in registers, then x' = rn(rn(R1 + h) + rn(X2 W^T + b)): one launch, no h round trip through HBM;
+//   bit 1  LayerNorm of the finished rows (the NEXT op of the block, ar_discrete.py:131,136,153) in the epilogue: the row
+//          moments are reduced in registers, across lanes and across the eight waves (LDS) in the exact order of
+//          layernorm_vec (wave_sum_up), so the output is bit-identical to the stand-alone LayerNorm launch it replaces;
+//   bit 2  a second LayerNorm of the same rows (norm2 | norm22);   bit 3  FiLM on the first (norm3, :145-156).
+template <typename T> struct RowPanelArgs {
+  const T* X2; const T* lnw; const T* lnb; const T* lnw2; const T* lnb2; const T* film; T* lny; T* lny2; float eps;
+};
+constexpr int FUSE_DUAL = 1, FUSE_LN = 2, FUSE_LN2 = 4, FUSE_FILM = 8;
+
+template <typename T, int EPI, int WM, int WN, int MODE, int FUSE = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                         const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                         const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                         int mask_period, int M, int N, int K, int n_tiles,
-                                                        int tiles_total, const uint16_t* __restrict__ gelu_tab_g) {
+                                                        int tiles_total, const uint16_t* __restrict__ gelu_tab_g,
+                                                        RowPanelArgs<T> rp) {
   constexpr int NW = WM * WN, TM = 96 * WM, TN = 64 * WN;   // 8 waves: one workgroup per CU; 4 waves: two
   constexpr int XD = TM / 8, WD = TN / 8;              // 1-KiB DMA pieces (8 rows x 128 B) per k-step and operand
   constexpr int XPW = (XD + NW - 1) / NW, WPW = WD / NW;   // pieces per wave
@@ -78,6 +92,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   constexpr int ABL = (MODE >> 4) & 3;
   constexpr bool kNoSync = (MODE & 64) != 0, kNoReads = (MODE & 128) != 0, kStamp = (MODE & 256) != 0;
   constexpr bool kPrioYoung = (MODE & 2) != 0, kPrioMfma = (MODE & 4) != 0, kDrip = (MODE & 8) != 0;
+  constexpr bool kDual = (FUSE & FUSE_DUAL) != 0, kLn = (FUSE & FUSE_LN) != 0, kLn2 = (FUSE & FUSE_LN2) != 0, kFilm = (FUSE & FUSE_FILM) != 0;
+  static_assert(FUSE == 0 || (WM == 1 && WN == 8 && !kDrip && (MODE & 1)), "row-panel fusion: 96 x 512 tiles, hand-placed schedule");
+  static_assert(!kLn2 || kLn, "the second LayerNorm shares the moments of the first");
   static_assert(!kDrip || kHand, "deferred stores ride in the hand-placed schedule");
   constexpr int SPS = 12 - NDMA;                        // deferred stores per k-step: the MFMA groups behind the last DMA piece
   constexpr int DRIP_STEPS = kDrip ? (12 + SPS - 1) / SPS : 0;          // 3 (192 x 256) or 6
@@ -243,6 +260,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    uintx4 h1p[kDual ? 12 : 1];
+    // the nk k-steps of one product: operand rows `ax`, weights `sw`; (nx, nw) = the first k-step of whatever follows
+    auto run_k = [&](const T* ax, const T* nx, const T* nw, auto FIRSTW) __attribute__((always_inline)) {
+      step(I0{}, FIRSTW, I0{}, I0{}, ax + BK, sw + BK);
+      step(I1{}, I0{}, I0{}, I0{}, ax + 2 * BK, sw + 2 * BK);
+      for (int kt = 2; kt < nk; kt += 2) {                  // nk is even and >= 4
+        step(I0{}, I0{}, I0{}, I0{}, ax + (kt + 1) * BK, sw + (kt + 1) * BK);
+        const bool last = kt + 2 >= nk;
+        step(I1{}, I0{}, I0{}, I0{}, last ? nx : ax + (kt + 2) * BK, last ? nw : sw + (kt + 2) * BK);
+      }
+    };
     if constexpr (kDrip) {
       static_for<PEEL>([&](auto SI) {                     // the k-steps that carry the previous tile's stores, written out
         constexpr int si = SI.value;
@@ -252,16 +280,149 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
         step(std::integral_constant<int, si & 1>{}, std::integral_constant<int, prev>{}, std::integral_constant<int, si * SPS>{},
              std::integral_constant<int, cnt>{}, lastk ? sx_next : sx + (si + 1) * BK, lastk ? sw_next : sw + (si + 1) * BK);
       });
+      for (int kt = PEEL; kt < nk; kt += 2) {               // nk is even and >= PEEL
+        step(I0{}, I0{}, I0{}, I0{}, sx + (kt + 1) * BK, sw + (kt + 1) * BK);
+        const bool last = kt + 2 >= nk;
+        step(I1{}, I0{}, I0{}, I0{}, last ? sx_next : sx + (kt + 2) * BK, last ? sw_next : sw + (kt + 2) * BK);
+      }
+    } else if constexpr (kDual) {
+      // two products through the same weights, one loop so that the k-step code exists once: phase 0 ends with its result
+      // packed in registers (h1p), phase 1 runs into the common epilogue below
+      const T* sx2 = rp.X2 + static_cast<size_t>(m0) * ldx;
+      const T* ax = sx;
+#pragma unroll 1
+      for (int ph = 0; ph < 2; ++ph) {
+        const bool mid = ph == 0;
+        run_k(ax, mid ? sx2 : sx_next, mid ? sw : sw_next, std::integral_constant<int, 12>{});
+        if (mid) {
+          epilogue_store<T, 0, 4, 6, true, true>(acc, bias, Y, ldy, nullptr, nullptr, ldr, nullptr, 1, M, N, m0, n0 + wn * 64, lane, h1p);
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing but the bias loads follows these DMA pieces: wait for all
+          ax = sx2;
+        }
+      }
     } else {
-      step(I0{}, std::integral_constant<int, 12>{}, I0{}, I0{}, sx + BK, sw + BK);   // behind an epilogue: its 12 stores may stay in flight
-      step(I1{}, I0{}, I0{}, I0{}, sx + 2 * BK, sw + 2 * BK);
+      run_k(sx, sx_next, sw_next, std::integral_constant<int, 12>{});
     }
-    for (int kt = PEEL; kt < nk; kt += 2) {               // nk is even and >= PEEL
-      step(I0{}, I0{}, I0{}, I0{}, sx + (kt + 1) * BK, sw + (kt + 1) * BK);
-      const bool last = kt + 2 >= nk;
-      step(I1{}, I0{}, I0{}, I0{}, last ? sx_next : sx + (kt + 2) * BK, last ? sw_next : sw + (kt + 2) * BK);
-    }
-    if (kDrip && more) {      // keep the finished tile in registers: its stores go out inside the next tile's first k-steps
+    if constexpr (FUSE != 0) {
+      uintx4 xp[12];
+      if constexpr (kDual) {
+        // x' = rn(rn(R1 + h) + rn(X2 W^T + b)): the R1 + R2 epilogue of the two-launch form with R2 = h taken from registers
+        epilogue_store<T, 0, 4, 6, true, true>(acc, bias, Y, ldy, nullptr, nullptr, ldr, nullptr, 1, M, N, m0, n0 + wn * 64, lane, xp);
+        const T* r1row = R1 + static_cast<size_t>(m0 + (lane & 15)) * ldr + n0 + wn * 64 + epilogue_nq(lane);
+        Pack8<T> r1p[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) r1p[j] = *reinterpret_cast<const Pack8<T>*>(r1row + static_cast<size_t>((j / 2) * 16) * ldr + (j % 2) * 32);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+          const Pack8<T> hh = __builtin_bit_cast(Pack8<T>, h1p[j]), yy = __builtin_bit_cast(Pack8<T>, xp[j]);
+          Pack8<T> o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            o.v[i] = static_cast<T>(rn<T>(static_cast<float>(r1p[j].v[i]) + static_cast<float>(hh.v[i])) + static_cast<float>(yy.v[i]));
+          xp[j] = __builtin_bit_cast(uintx4, o);
+        }
+      } else {
+        epilogue_store<T, EPI, 4, 6, true, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0, n0 + wn * 64, lane, xp);
+      }
+      // ---- the finished rows: store x', then LayerNorm them in place (layernorm_vec's arithmetic, bit for bit)
+      const int g = lane >> 4, nq = epilogue_nq(lane);
+      T* yrow = Y + static_cast<size_t>(m0 + (lane & 15)) * ldy + n0 + wn * 64 + nq;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) *reinterpret_cast<uintx4*>(yrow + static_cast<size_t>((j / 2) * 16) * ldy + (j % 2) * 32) = xp[j];
+      if constexpr (kLn) {
+        float* red = reinterpret_cast<float*>(smem + 2 * STAGE);              // [2][96 rows][8 waves] partial sums
+        auto unpack = [&](int j, float (&v)[8]) __attribute__((always_inline)) {
+          const Pack8<T> p = __builtin_bit_cast(Pack8<T>, xp[j]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(p.v[i]);
+        };
+        // a row's 512 columns = 64 chunks of 8; this lane holds chunks c = 8 wave + 4 np + 2 (g & 1) + (g >> 1) of rows
+        // (lane & 15) + 16 mt.  wave_sum_up's tree over the chunk index: bit 0 = lane ^ 32, bit 1 = lane ^ 16, bit 2 = np,
+        // bits 3..5 = the wave (through LDS), each level adding the two halves exactly as the 64-lane butterfly does
+        auto row_total = [&](float (&part)[6][2], int which, float (&tot)[6]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int mt = 0; mt < 6; ++mt) {
+            float a0 = part[mt][0], a1 = part[mt][1];
+            a0 += __shfl_xor(a0, 32, kWave); a1 += __shfl_xor(a1, 32, kWave);
+            a0 += __shfl_xor(a0, 16, kWave); a1 += __shfl_xor(a1, 16, kWave);
+            const float w8 = a0 + a1;
+            if (g == 0) red[(which * 96 + mt * 16 + (lane & 15)) * 8 + wave] = w8;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int mt = 0; mt < 6; ++mt) {
+            const floatx4 lo4 = *reinterpret_cast<const floatx4*>(red + (which * 96 + mt * 16 + (lane & 15)) * 8);
+            const floatx4 hi4 = *reinterpret_cast<const floatx4*>(red + (which * 96 + mt * 16 + (lane & 15)) * 8 + 4);
+            tot[mt] = ((lo4[0] + lo4[1]) + (lo4[2] + lo4[3])) + ((hi4[0] + hi4[1]) + (hi4[2] + hi4[3]));
+          }
+        };
+        float part[6][2], mean[6], rstd[6];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+          for (int np = 0; np < 2; ++np) {
+            float v[8], s1 = 0.f;
+            unpack(mt * 2 + np, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s1 += v[i];
+            part[mt][np] = s1;
+          }
+        row_total(part, 0, mean);
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) mean[mt] = mean[mt] / 512.0f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+          for (int np = 0; np < 2; ++np) {
+            float v[8], q = 0.f;
+            unpack(mt * 2 + np, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float tt = v[i] - mean[mt]; q += tt * tt; }
+            part[mt][np] = q;
+          }
+        row_total(part, 1, rstd);
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) rstd[mt] = rsqrtf(rstd[mt] / 512.0f + rp.eps);
+#pragma unroll
+        for (int np = 0; np < 2; ++np) {
+          const int col = n0 + wn * 64 + np * 32 + nq;
+          const Pack8<T> wv = *reinterpret_cast<const Pack8<T>*>(rp.lnw + col), bv = *reinterpret_cast<const Pack8<T>*>(rp.lnb + col);
+          Pack8<T> sc, sh, w2v, b2v;
+          if constexpr (kFilm) { sc = *reinterpret_cast<const Pack8<T>*>(rp.film + col); sh = *reinterpret_cast<const Pack8<T>*>(rp.film + 512 + col); }
+          if constexpr (kLn2) { w2v = *reinterpret_cast<const Pack8<T>*>(rp.lnw2 + col); b2v = *reinterpret_cast<const Pack8<T>*>(rp.lnb2 + col); }
+#pragma unroll
+          for (int mt = 0; mt < 6; ++mt) {
+            float v[8], nrm[8];
+            unpack(mt * 2 + np, v);
+            Pack8<T> o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              nrm[i] = (v[i] - mean[mt]) * rstd[mt];
+              o.v[i] = static_cast<T>(nrm[i] * static_cast<float>(wv.v[i]) + static_cast<float>(bv.v[i]));
+            }
+            if constexpr (kFilm) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const float gg = rn<T>(1.0f + static_cast<float>(sc.v[i]));
+                o.v[i] = static_cast<T>(rn<T>(static_cast<float>(o.v[i]) * gg) + static_cast<float>(sh.v[i]));
+              }
+            }
+            const size_t off = static_cast<size_t>(m0 + mt * 16 + (lane & 15)) * 512 + col;
+            *reinterpret_cast<Pack8<T>*>(rp.lny + off) = o;
+            if constexpr (kLn2) {
+              Pack8<T> o2;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) o2.v[i] = static_cast<T>(nrm[i] * static_cast<float>(w2v.v[i]) + static_cast<float>(b2v.v[i]));
+              *reinterpret_cast<Pack8<T>*>(rp.lny2 + off) = o2;
+            }
+          }
+        }
+      }
+    } else if (kDrip && more) {      // keep the finished tile in registers: its stores go out inside the next tile's first k-steps
       epilogue_store<T, EPI, 4, 6, true, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
                                                n0 + wn * 64, lane, pend, gelu_tab);
       pend_y = Y + static_cast<size_t>(m0 + wm * 96 + (lane & 15)) * ldy + n0 + wn * 64 + epilogue_nq(lane);
@@ -357,7 +518,7 @@ static int big_launch(const LinearArgs& a, int n_tiles, int tiles_total, dim3 gr
   gemm_mfma_big<U, E, WM, WN, MD><<<grid, dim3(WM * WN * 64), lds, s>>>(
       static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
       static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles,
-      tiles_total, tab);
+      tiles_total, tab, RowPanelArgs<U>{});
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;
 }
@@ -414,6 +575,66 @@ int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s) {
       case EPI_R1 | EPI_MASK: return big_launch_geometry<U, EPI_R1 | EPI_MASK>(id, a, n_tiles, tiles_total, grid, lds, s);
       default: break;
     }
+    return D3PM_E_SHAPE;
+  };
+  return dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
+}
+
+// ---- row-panel fusion: projection onto the residual stream + the LayerNorm(s) that read it next, one launch ----------
+// Instantiated: out-proj + x -> norm2 | norm22 (EPI_R1, two LayerNorms); both cross-attention out-projections + x -> norm3 with
+// FiLM (EPI_R2 from registers); fc2 + x, frame mask -> the next block's norm1 (EPI_R1 | EPI_MASK).
+static int row_panel_kind(const LinearArgs& a, const RowPanelFuse& f) {
+  const bool r1 = a.R1 != nullptr, mk = a.row_mask != nullptr, dual = f.X2 != nullptr, ln2 = f.lnw2 != nullptr, film = f.film != nullptr;
+  if (!r1 || a.R2 || !f.lnw || !f.lnb || !f.lny || a.act != ACT_NONE) return 0;
+  if (ln2 != (f.lnb2 != nullptr) || ln2 != (f.lny2 != nullptr)) return 0;
+  if (!dual && !mk && ln2 && !film) return 1;
+  if (dual && !mk && !ln2 && film) return 2;
+  if (!dual && mk && !ln2 && !film) return 3;
+  return 0;
+}
+
+bool row_panel_supported(int dtype, const LinearArgs& a, const RowPanelFuse& f) {
+  if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
+  if (a.N != 512 || a.ldy != 512 || a.ldr != 512 || a.M < 96 || a.M % 96 != 0 || a.K < 4 * BK || a.K % (2 * BK) != 0) return false;
+  if (a.ldx % 8 != 0 || a.ldx >= (1 << 24) || a.K >= (1 << 24) || !a.bias) return false;
+  for (const void* p : {a.X, a.W, static_cast<const void*>(a.Y), a.R1, a.bias, f.X2, f.lnw, f.lnb, f.lnw2, f.lnb2, f.film,
+                        static_cast<const void*>(f.lny), static_cast<const void*>(f.lny2)})
+    if (!aligned16(p)) return false;
+  return row_panel_kind(a, f) != 0;
+}
+
+template <typename U, int E, int FUSE>
+static int row_panel_launch(const LinearArgs& a, const RowPanelFuse& f, hipStream_t s) {
+  const int tiles_total = a.M / 96, want = (tiles_total + 7) & ~7;
+  const dim3 grid(static_cast<unsigned>(want < 256 ? want : 256));
+  const size_t lds = 2 * static_cast<size_t>(96 + 512) * ROW_BYTES + 2 * 96 * 8 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_big<U, E, 1, 8, 1, FUSE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  RowPanelArgs<U> rp{static_cast<const U*>(f.X2), static_cast<const U*>(f.lnw), static_cast<const U*>(f.lnb),
+                     static_cast<const U*>(f.lnw2), static_cast<const U*>(f.lnb2), static_cast<const U*>(f.film),
+                     static_cast<U*>(f.lny), static_cast<U*>(f.lny2), f.eps};
+  gemm_mfma_big<U, E, 1, 8, 1, FUSE><<<grid, dim3(512), lds, s>>>(
+      static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
+      static_cast<const U*>(a.R1), nullptr, a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, 1, tiles_total, nullptr, rp);
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+int row_panel_linear(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s) {
+  const int kind = row_panel_kind(a, f);
+  auto go = [&](auto* tag) -> int {
+    using U = std::remove_pointer_t<decltype(tag)>;
+    switch (kind) {
+      case 1: return row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2>(a, f, s);
+      case 2: return row_panel_launch<U, EPI_R2, FUSE_DUAL | FUSE_LN | FUSE_FILM>(a, f, s);
+      case 3: return row_panel_launch<U, EPI_R1 | EPI_MASK, FUSE_LN>(a, f, s);
+      default: break;
+    }
+    set_error("row-panel projection: unsupported epilogue combination");
     return D3PM_E_SHAPE;
   };
   return dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));

@@ -134,6 +134,9 @@ SIGNATURES = {
                                     C.c_void_p]),
     "d3pm_op_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_float, C.c_void_p]),
+    "d3pm_op_linear_rowpanel": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "d3pm_op_cond_embed": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p]),
     "d3pm_op_matmul_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_int, C.c_int,
@@ -597,6 +600,22 @@ def op_layernorm(x, w, b, film=None, eps=1e-6):
     return y
 
 
+def op_linear_rowpanel(x, w, bias, r1, ln_w, ln_b, *, x2=None, ln2_w=None, ln2_b=None, film=None, row_mask=None, eps=1e-6):
+    """Projection onto the residual stream + the LayerNorm(s) of the new rows in one launch (include/d3pm_hip.h).
+    Returns (y, ln_y, ln2_y | None)."""
+    M, K = x.shape
+    if not (tuple(w.shape) == (512, K) and tuple(r1.shape) == (M, 512) and x.stride(1) == 1 and w.is_contiguous() and r1.is_contiguous()):
+        raise ValueError("op_linear_rowpanel: x [M,K], w [512,K], r1 [M,512]")
+    if x2 is not None and (x2.shape != x.shape or x2.stride() != x.stride()):
+        raise ValueError("op_linear_rowpanel: x2 must look like x")
+    y, ln_y = torch.empty_like(r1), torch.empty_like(r1)
+    ln2_y = torch.empty_like(r1) if ln2_w is not None else None
+    check(lib().d3pm_op_linear_rowpanel(dtype_code(x.dtype), _p(x), _p(x2), x.stride(0), _p(w), _p(bias), _p(y), _p(r1), _p(row_mask),
+                                        0 if row_mask is None else row_mask.numel(), M, K, _p(ln_w), _p(ln_b), _p(ln_y),
+                                        _p(ln2_w), _p(ln2_b), _p(ln2_y), _p(film), eps, stream_ptr()), "d3pm_op_linear_rowpanel")
+    return y, ln_y, ln2_y
+
+
 class NarRunner:
     """Pointer tables + workspace of the stock NAR model (d3pm_nar_level)."""
 
@@ -656,6 +675,10 @@ def set_attn_query_groups(v: int):
 
 def set_attn_pair_sequential(v: bool):
     check(lib().d3pm_set_tuning(3, 1 if v else 0), "d3pm_set_tuning")
+
+
+def set_row_panel(mask: int):
+    check(lib().d3pm_set_tuning(8, int(mask)), "d3pm_set_tuning")
 
 
 def set_gelu_table(v: bool):
