@@ -301,6 +301,15 @@ int d3pm_op_attention(int dtype, int family, const void *Q, int ldq, const void 
                       void *O, int ldo, int B, int Tq, int S, int H, int hd, float scale, void *stream);
 int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const void *b, const void *film,
                       int M, int d, float eps, void *stream);
+/* LayerNorm-prologue projection (d_model = 512, latency regime): Y[M][N] = act(LN(X) W^T + bias) with X [.][512] the
+ * UN-normalised residual stream -- the 64-row operand panels of the latency GEMM are whole rows, so each workgroup normalises
+ * them in LDS before its MFMAs (ar_discrete.py:131-132 norm1 -> self-attention in-projection, :145-159 norm3 + FiLM -> fc1).
+ * With ln2_w / ln2_b: M = 2 m rows, output rows >= m are source rows 0 .. m-1 under the second LayerNorm (:136-142, norm2 |
+ * norm22 -> the text and prompt query projections through the shared cross_attn weights).  Bit-identical to
+ * d3pm_op_layernorm followed by d3pm_op_linear.  W [N][512], Y [M][N], act 0 none / 1 GELU. */
+int d3pm_op_linear_lnpro(int dtype, const void *X, const void *W, const void *bias, void *Y, int M, int N, int act,
+                         const void *ln_w, const void *ln_b, const void *ln2_w, const void *ln2_b, const void *film,
+                         float eps, void *stream);
 /* Row-panel projection (d_model = 512): a Linear whose output is added to the residual stream, together with the LayerNorm(s)
  * the block applies to the new rows next, in ONE launch -- a workgroup owns whole rows (96 x 512 tiles), so the row moments
  * are reduced on chip.  Three forms, each bit-identical to the launches it replaces (d3pm_op_linear, then d3pm_op_layernorm):
@@ -346,6 +355,9 @@ int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, c
  *                         kernel and the logits never reach HBM (16-bit model, d_model a multiple of 32, MFMA family);
  *                         0 (default: measured faster) = the two-launch form (final GEMM, then d3pm_posterior_sample's
  *                         kernel).  Same ids either way.
+ * D3PM_TUNE_LN_PROLOGUE:  1 (default) = wherever the latency GEMM (64 x 64 tiles, M <= 1536 rows) runs a LayerNorm-fed projection
+ *                         of a d_model = 512 block, the LayerNorm is that launch's prologue (d3pm_op_linear_lnpro); 0 = separate
+ *                         LayerNorm launches.  Same results.
  * D3PM_TUNE_ROW_PANEL:    bit mask of the block's projections that run as row-panel launches (d3pm_op_linear_rowpanel) when
  *                         d_model = 512, the dtype is 16-bit and batch * canvas is a multiple of 96: 1 = self-attention
  *                         out-projection + norm2 | norm22, 2 = both cross-attention out-projections + norm3 / FiLM, 4 = fc2 +
@@ -356,7 +368,7 @@ int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, c
  *                         MFMA, 64 no barriers, 128 no LDS reads, 256 clock stamp for d3pm_debug_gemm_clock). */
 enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2,
        D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4, D3PM_TUNE_FUSED_FINAL_SAMPLE = 5,
-       D3PM_TUNE_ATTN_CROSS_RESIDENT = 6, D3PM_TUNE_GELU_TABLE = 7, D3PM_TUNE_ROW_PANEL = 8 };
+       D3PM_TUNE_ATTN_CROSS_RESIDENT = 6, D3PM_TUNE_GELU_TABLE = 7, D3PM_TUNE_ROW_PANEL = 8, D3PM_TUNE_LN_PROLOGUE = 9 };
 int d3pm_set_tuning(int knob, int value);
 
 /* Single-op entry of the fused final projection + posterior + draw (replaces `final` at ar_discrete.py:776 followed by

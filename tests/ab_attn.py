@@ -1,0 +1,45 @@
+"""Timing-only ablations of the MFMA self-attention kernel (not a test): python tests/ab_attn.py
+Arms: the shipped kernel and builds with parts removed (WRONG results) -- what each part costs in place."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tts-with-diffusion-model_amd"), ROOT]
+import __graft_entry__ as g  # noqa: E402
+
+g.build()
+from vall_e.vall_e import _hip  # noqa: E402
+
+DEV = "cuda:0"
+B, T, H, d = 32, 768, 8, 512
+torch.manual_seed(0)
+qkv = torch.randn(B, T, 3 * d, device=DEV).to(torch.bfloat16)
+q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+
+
+def timeit(fn, reps=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+ARMS = [(2, "shipped (QG 2)"), (1, "QG 1"), (101, "no v_exp"), (102, "no max / rescale"), (103, "no exp, no max"), (104, "no staging"),
+        (112, "no staging, no barriers"), (116, "no P.V"), (132, "no Q.K"), (148, "no MFMA products"), (115, "only the MFMA products"),
+        (160, "only softmax VALU")]
+arms = [int(a) for a in sys.argv[1:]] or [a for a, _ in ARMS]
+names = dict(ARMS)
+flops = 4.0 * B * H * T * T * 64
+for arm in arms:
+    _hip.set_attn_query_groups(arm) if arm < 100 else _hip.check(_hip.lib().d3pm_set_tuning(1, arm), "tune")
+    t = timeit(lambda: _hip.op_attention(q, k, v, H, 0.125, family=_hip.FAMILY_MFMA))
+    print("%-28s %7.1f us  %6.0f TFLOP/s-equivalent" % (names.get(arm, str(arm)), t, flops / t / 1e6), flush=True)
+_hip.set_attn_query_groups(0)

@@ -446,3 +446,52 @@ def test_sample_loop_is_the_same_with_and_without_row_panel_launches(built_lib):
         _hip.set_row_panel(3)
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("form,m,N", [("norm1_qkv", 768, 1536), ("norm2_norm22_q", 768, 512), ("norm3_film_fc1", 768, 2048),
+                                      ("norm1_qkv", 100, 1536), ("norm2_norm22_q", 128, 512), ("norm3_film_fc1", 1500, 2048)])
+def test_layernorm_prologue_projection_equals_layernorm_then_linear(built_lib, dtype, form, m, N):
+    """d3pm_op_linear_lnpro (the latency GEMM normalising its operand rows in LDS) against d3pm_op_layernorm followed by
+    d3pm_op_linear: same bits, for the three LayerNorm-fed projections of a block, whole and ragged row counts."""
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(m + N)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dtype).to(DEV)
+    x = mk(m, 512, sc=2.0) + 0.25
+    w, b = mk(N, 512, sc=1.0 / math.sqrt(512)), mk(N, sc=0.3)
+    lw, lb, lw2, lb2, film = mk(512, sc=0.5) + 1, mk(512, sc=0.2), mk(512, sc=0.5) + 1, mk(512, sc=0.2), mk(1024, sc=0.3)
+    try:
+        _hip.set_gemm_variant(4)          # the reference launches on the same schedule family (all are bit-identical anyway)
+        if form == "norm1_qkv":
+            y = _hip.op_linear_lnpro(x, w, b, lw, lb)
+            ref = _hip.op_linear(_hip.op_layernorm(x, lw, lb), w, b, family=_hip.FAMILY_MFMA)
+        elif form == "norm2_norm22_q":
+            y = _hip.op_linear_lnpro(x, w, b, lw, lb, ln2_w=lw2, ln2_b=lb2)
+            h = torch.cat([_hip.op_layernorm(x, lw, lb), _hip.op_layernorm(x, lw2, lb2)])
+            ref = _hip.op_linear(h, w, b, family=_hip.FAMILY_MFMA)
+        else:
+            y = _hip.op_linear_lnpro(x, w, b, lw, lb, film=film, act=1)
+            ref = _hip.op_linear(_hip.op_layernorm(x, lw, lb, film=film), w, b, act=1, family=_hip.FAMILY_MFMA)
+    finally:
+        _hip.set_gemm_variant(0)
+    assert y.shape == ref.shape
+    assert torch.equal(y, ref), f"{form}: {(y != ref).sum().item()} of {y.numel()} elements differ"
+
+
+def test_generate_audio_is_the_same_with_and_without_layernorm_prologues(built_lib):
+    """D3PM_TUNE_LN_PROLOGUE inside the loop at one and two utterances (the regime it applies to)."""
+    from vall_e.vall_e import AR, _hip, synth
+    cfg = synth.D3PMConfig.libritts()
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0))
+    m = m.to(torch.bfloat16).to(DEV)
+    for batch in (1, 2):
+        texts, proms = synth.make_inputs(cfg, batch, 1)
+        try:
+            _hip.set_ln_prologue(False)
+            a = m.generate_audio(texts, proms, steps=4, seed=4)
+            _hip.set_ln_prologue(True)
+            b = m.generate_audio(texts, proms, steps=4, seed=4)
+        finally:
+            _hip.set_ln_prologue(True)
+        assert torch.equal(a, b)

@@ -89,6 +89,15 @@ static int run_linear(int dtype, const LinearArgs& a, uint32_t flags, hipStream_
   if (!(flags & D3PM_FLAG_FORCE_GENERIC) && mfma_linear_supported(dtype, a)) return mfma_linear(dtype, a, s);
   return generic_linear(dtype, a, s);
 }
+// D3PM_TUNE_LN_PROLOGUE: at one or two utterances the LayerNorm-fed projections normalise their operand rows themselves
+static int g_ln_prologue = 0;
+// LayerNorm + projection in one launch of the latency GEMM (d3pm_mfma_gemm_lat.hip); a.X is the un-normalised stream
+static int run_ln_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, hipStream_t s) {
+  const size_t es = dtype_size(dtype);
+  ProfScope p(D3PM_K_GEMM, s, 2.0 * a.M * a.N * a.K,
+              es * (static_cast<double>(ln.period ? ln.period : a.M) * a.K + static_cast<double>(a.N) * a.K + static_cast<double>(a.M) * a.N));
+  return ln_prologue_linear(dtype, a, ln, s);
+}
 // projection onto the residual stream + the LayerNorm(s) of the new rows, one launch (d3pm_mfma_gemm_big.hip)
 static int run_row_panel(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s) {
   const size_t es = dtype_size(dtype);
@@ -194,6 +203,8 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
   const bool rp_fills = n % 96 == 0 && rp_tiles * 5 >= 256 * 4 && rp_tiles * 100 >= rp_rounds * 256 * 85;
   const int panel = (!use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && rp_fills && (dt == D3PM_F16 || dt == D3PM_BF16)) ? g_row_panel : 0;
   bool norm1_done = false;      // the previous block's fc2 launch already wrote norm1(x) of this block to ws.h
+  // the opposite regime (one or two utterances, latency GEMM): LayerNorm runs as the prologue of the projection it feeds
+  const bool lnpro = g_ln_prologue && !use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && (dt == D3PM_F16 || dt == D3PM_BF16);
 
   for (int l = 0; l < layers; ++l) {
     const d3pm_block_weights& b = w.blocks[l];
@@ -209,8 +220,16 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].attn_in_w8), f8[l].attn_in_scale, b.attn_in_b, ws.qkv,
                           3 * d, n, 3 * d, d, ACT_NONE, s));
     } else {
-      if (!norm1_done) D3PM_TRY(run_layernorm(dt, ln, flags, s));
-      D3PM_TRY(run_linear(dt, g, flags, s));
+      LnPrologue lp;
+      lp.w = ln.w; lp.b = ln.b; lp.eps = ln.eps;
+      LinearArgs gx = g;
+      gx.X = ws.x;
+      if (!norm1_done && lnpro && ln_prologue_linear_applies(dt, gx, lp)) {
+        D3PM_TRY(run_ln_linear(dt, gx, lp, s));
+      } else {
+        if (!norm1_done) D3PM_TRY(run_layernorm(dt, ln, flags, s));
+        D3PM_TRY(run_linear(dt, g, flags, s));
+      }
     }
     norm1_done = false;
     AttnArgs a;
@@ -239,12 +258,20 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].cross_in_w8), f8[l].cross_in_scale, b.cross_in_b,
                           q_text, d, 2 * n, d, d, ACT_NONE, s));
     } else if (ws.h2 == at(ws.h, static_cast<size_t>(n) * d, es)) {
-      if (!norm2_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
       // both query projections share cross_attn's q rows: LN2|LN22 outputs and q_text|q_prompt are adjacent in
       // the workspace, so the pair is ONE [2n, d] x [d, d] GEMM (twice the workgroups of either alone)
       g = LinearArgs();
       g.X = ws.h; g.ldx = d; g.W = b.cross_in_w; g.bias = b.cross_in_b; g.Y = q_text; g.ldy = d; g.M = 2 * n; g.N = d; g.K = d;
-      D3PM_TRY(run_linear(dt, g, flags, s));
+      LnPrologue lp;
+      lp.w = ln.w; lp.b = ln.b; lp.w2 = ln.w2; lp.b2 = ln.b2; lp.eps = ln.eps; lp.period = n;
+      LinearArgs gx = g;
+      gx.X = ws.x;
+      if (!norm2_fused && lnpro && ln_prologue_linear_applies(dt, gx, lp)) {
+        D3PM_TRY(run_ln_linear(dt, gx, lp, s));
+      } else {
+        if (!norm2_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
+        D3PM_TRY(run_linear(dt, g, flags, s));
+      }
     } else {
       if (!norm2_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
       for (int which = 0; which < 2; ++which) {
@@ -294,8 +321,16 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].fc1_w8), f8[l].fc1_scale, b.fc1_b, ws.mlp, 4 * d, n,
                           4 * d, d, ACT_GELU, s));
     } else {
-      if (!norm3_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
-      D3PM_TRY(run_linear(dt, g, flags, s));
+      LnPrologue lp;
+      lp.w = ln.w; lp.b = ln.b; lp.film = ln.film; lp.eps = ln.eps;
+      LinearArgs gx = g;
+      gx.X = ws.x;
+      if (!norm3_fused && lnpro && ln_prologue_linear_applies(dt, gx, lp)) {
+        D3PM_TRY(run_ln_linear(dt, gx, lp, s));
+      } else {
+        if (!norm3_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
+        D3PM_TRY(run_linear(dt, g, flags, s));
+      }
     }
     g = LinearArgs();
     g.X = ws.mlp; g.ldx = 4 * d; g.W = b.fc2_w; g.bias = b.fc2_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
@@ -742,6 +777,19 @@ int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const vo
   return run_layernorm(dtype, ln, 0, static_cast<hipStream_t>(stream));
 }
 
+int d3pm_op_linear_lnpro(int dtype, const void* X, const void* W, const void* bias, void* Y, int M, int N, int act, const void* ln_w,
+                         const void* ln_b, const void* ln2_w, const void* ln2_b, const void* film, float eps, void* stream) {
+  D3PM_REQUIRE(X && W && Y && ln_w && ln_b && M > 0 && N > 0, D3PM_E_ARG, "d3pm_op_linear_lnpro: bad arguments");
+  LinearArgs g;
+  g.X = X; g.ldx = 512; g.W = W; g.bias = bias; g.Y = Y; g.ldy = N; g.M = M; g.N = N; g.K = 512; g.act = act;
+  LnPrologue lp;
+  lp.w = ln_w; lp.b = ln_b; lp.w2 = ln2_w; lp.b2 = ln2_b; lp.film = film; lp.eps = eps; lp.period = ln2_w ? M / 2 : 0;
+  D3PM_REQUIRE(panel64_ln_supported(dtype, g, lp), D3PM_E_SHAPE,
+               "d3pm_op_linear_lnpro: needs a 16-bit dtype, 16-byte aligned operands, N a multiple of 8, act 0 / 1 and, with a second "
+               "LayerNorm, M = 2 x a multiple of 64 rows and no FiLM");
+  return ln_prologue_linear(dtype, g, lp, static_cast<hipStream_t>(stream));
+}
+
 int d3pm_op_linear_rowpanel(int dtype, const void* X, const void* X2, int ldx, const void* W, const void* bias, void* Y, const void* R1,
                             const uint8_t* row_mask, int mask_period, int M, int K, const void* ln_w, const void* ln_b, void* ln_y,
                             const void* ln2_w, const void* ln2_b, void* ln2_y, const void* film, float eps, void* stream) {
@@ -784,12 +832,13 @@ int d3pm_op_cond_embed(int dtype, int which, const int32_t* tokens, int n_levels
 
 int d3pm_set_tuning(int knob, int value) {
   if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || (value >= 2 && value <= 8))) { set_gemm_variant(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && value >= 0 && value <= 2) { set_attn_qg(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && ((value >= 0 && value <= 2) || (value >= 100 && value < 164))) { set_attn_qg(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && (value == 0 || value == 1)) { set_attn_pair_sequential(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 9 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465)) { set_big_gemm_mode(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GELU_TABLE && (value == 0 || value == 1)) { set_gelu_table(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_CROSS_RESIDENT && (value == 0 || value == 1)) { set_attn_cross_resident(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_FUSED_FINAL_SAMPLE && (value == 0 || value == 1)) { g_fused_final_sample = value; return D3PM_OK; }
+  if (knob == D3PM_TUNE_LN_PROLOGUE && (value == 0 || value == 1)) { g_ln_prologue = value; return D3PM_OK; }
   if (knob == D3PM_TUNE_ROW_PANEL && value >= 0 && value <= 7) { g_row_panel = value; return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_PERSIST_SLOTS && value >= 8 && value <= 4096 && value % 8 == 0) { set_gemm_persist_slots(value); return D3PM_OK; }
   set_error("d3pm_set_tuning: unknown knob %d / value %d", knob, value);

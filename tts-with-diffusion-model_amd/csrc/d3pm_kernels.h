@@ -61,6 +61,13 @@ struct RowPanelFuse {
   float eps = 1e-6f;
 };
 
+// LayerNorm applied to the operand rows inside the latency GEMM (d3pm_mfma_gemm_lat.hip): X is then the residual stream.
+// period > 0: M = 2 * period rows, rows >= period re-read source row m - period under the second LayerNorm (w2, b2).
+struct LnPrologue {
+  const void* w = nullptr; const void* b = nullptr; const void* w2 = nullptr; const void* b2 = nullptr;
+  const void* film = nullptr; float eps = 1e-6f; int period = 0;
+};
+
 struct EmbedArgs {
   const int32_t* tokens = nullptr; const uint8_t* frame_mask = nullptr; int canvas = 0;
   const void* table = nullptr; void* Y = nullptr; int M = 0, d = 0, n_classes = 0;
@@ -110,6 +117,9 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a);
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s);
 bool mfma_attention_supported(int dtype, const AttnArgs& a);
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s);
+bool panel64_ln_supported(int dtype, const LinearArgs& a, const LnPrologue& ln);
+bool ln_prologue_linear_applies(int dtype, const LinearArgs& a, const LnPrologue& ln);   // would mfma_linear pick the latency GEMM?
+int ln_prologue_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, hipStream_t s);
 bool row_panel_supported(int dtype, const LinearArgs& a, const RowPanelFuse& f);
 int row_panel_linear(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s);
 bool fast_layernorm_supported(int dtype, const LayerNormArgs& a);

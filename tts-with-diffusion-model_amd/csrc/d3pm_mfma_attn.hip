@@ -71,7 +71,9 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2v){a, b}, pair));
 }
 
-template <typename T, int QG, bool PAIR>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
+// ABL: timing-only ablation builds (WRONG results; tests/ab_attn.py): 1 no v_exp, 2 no maximum / rescale logic, 4 no K/V
+// staging after the first tile, 8 no barriers, 16 no P.V product, 32 no Q.K product
+template <typename T, int QG, bool PAIR, int ABL = 0>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
 __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
                                                       const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo,
                                                       int Tq, int S, float scale, int H, int n_qblocks,
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
     const char* kb = smem + (tile & 1) * 2 * TILE;
     const char* vb = kb + TILE;
     const bool more = tile + 1 < n_tiles;
-    if (more) st = load_tile(tile + 1);
+    if (more && !(ABL & 4)) st = load_tile(tile + 1);
 
     // ---- S^T tile: 64 keys x (16 QG) queries per wave; each K fragment feeds QG MFMAs ----
     // The accumulator starts at -m_ref (one register quad per query group, shared by the four key tiles as the C
@@ -182,9 +184,14 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (ABL & 32) {
+#pragma unroll
+          for (int qg = 0; qg < QG; ++qg) s[qg][kt] = negm[qg] + floatx4{0.1f * kt, 0.2f, 0.3f * tile, 0.4f};
+        } else {
         uint4 kf = *reinterpret_cast<const uint4*>(kb + k_off(kt * 16 + qi, ks * 4 + g));
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) s[qg][kt] = mma<T>(kf, qf[qg][ks], ks == 0 ? negm[qg] : s[qg][kt]);
+        }
       }
     // lane holds scores (log2 domain, minus m_ref) of its query for keys tile*64 + kt*16 + 4g + r
     const bool ragged = (tile == n_tiles - 1) && (S & (BKV - 1));   // wave-uniform: only the last tile can be partial
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
       // Deferred maximum: m_ref only moves when some score of the wave exceeds it by more than 2^kDefer (or on the
       // first tile), so the common tile does neither the cross-lane maximum nor the rescale of O; probabilities are
       // then at most 2^kDefer instead of 1, which neither fp32 sums nor 16-bit P notice (normalised by the same sum).
-      if (tile == 0 || __any(mx > kDefer)) {               // wave-uniform
+      if (!(ABL & 2) && (tile == 0 || __any(mx > kDefer))) {               // wave-uniform
         mx = max_over_query_lanes(mx);                     // lanes l, l^16, l^32, l^48 share a query
         const float delta = tile == 0 ? mx : fmaxf(mx, 0.f);
 #pragma unroll
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[qg][kt][r] = __builtin_amdgcn_exp2f(s[qg][kt][r]);
+        for (int r = 0; r < 4; ++r) s[qg][kt][r] = (ABL & 1) ? s[qg][kt][r] : __builtin_amdgcn_exp2f(s[qg][kt][r]);
       // contraction index j<4 -> key tile 2kb, j>=4 -> key tile 2kb+1 (same permutation as the V reads)
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
@@ -240,6 +247,16 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
     }
 
     // ---- O^T += V^T . P^T ; each transposed V fragment feeds QG MFMAs ----
+    if constexpr (ABL & 16) {
+#pragma unroll
+      for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+          acc_o[qg][kb2][0] += __builtin_bit_cast(float, pf[qg][kb2].x); acc_o[qg][kb2][1] += __builtin_bit_cast(float, pf[qg][kb2].y);
+          acc_o[qg][kb2][2] += __builtin_bit_cast(float, pf[qg][kb2].z); acc_o[qg][kb2][3] += __builtin_bit_cast(float, pf[qg][kb2].w);
+          acc_l[qg][0] += 1.0f;
+        }
+    } else {
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
@@ -261,8 +278,9 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
     for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
       for (int qg = 0; qg < QG; ++qg) acc_l[qg] = mma<T>(ones, pf[qg][kb2], acc_l[qg]);
-    if (more) store_tile(smem + ((tile + 1) & 1) * 2 * TILE, st);
-    __syncthreads();
+    }
+    if (more && !(ABL & 4)) store_tile(smem + ((tile + 1) & 1) * 2 * TILE, st);
+    if constexpr (!(ABL & 8)) __syncthreads();
   }
 
 #pragma unroll
@@ -505,7 +523,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     return D3PM_OK;
   }
   const long long wgs2 = static_cast<long long>((a.Tq + 127) / 128) * a.H * a.B * (a.Q2 ? 2 : 1);
-  const int qg = g_attn_qg == 0 ? (wgs2 >= 4 * 256 ? 2 : 1) : g_attn_qg, per_block = 64 * qg;
+  const int qg = g_attn_qg == 0 ? (wgs2 >= 4 * 256 ? 2 : 1) : g_attn_qg >= 100 ? 2 : g_attn_qg, per_block = 64 * qg;
   const int n_qblocks = (a.Tq + per_block - 1) / per_block;
   const int n_blocks1 = n_qblocks * a.H * a.B;
   const bool seq = a.Q2 != nullptr && g_attn_pair_seq;
@@ -522,7 +540,15 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     if (seq) { if (qg == 1) D3PM_ATTN(T, 1, true); else D3PM_ATTN(T, 2, true); }           \
     else { if (qg == 1) D3PM_ATTN(T, 1, false); else D3PM_ATTN(T, 2, false); }             \
   } while (0)
-  if (dtype == D3PM_F16) D3PM_ATTN_QG(f16); else D3PM_ATTN_QG(bf16);
+  if (g_attn_qg >= 100 && dtype == D3PM_BF16 && !a.Q2) {      // timing-only ablations of the QG = 2 kernel
+#define D3PM_ABL(A) case A: attn_mfma_hd64<bf16, 2, false, A><<<grid, block, 0, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), \
+      static_cast<const bf16*>(a.V), a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks, nullptr, nullptr, nullptr, nullptr, 0, n_first, a.key_len); break
+    switch (g_attn_qg - 100) {
+      D3PM_ABL(1); D3PM_ABL(2); D3PM_ABL(3); D3PM_ABL(4); D3PM_ABL(12); D3PM_ABL(16); D3PM_ABL(32); D3PM_ABL(48); D3PM_ABL(15); D3PM_ABL(60);
+      default: D3PM_ATTN(bf16, 2, false);
+    }
+#undef D3PM_ABL
+  } else if (dtype == D3PM_F16) D3PM_ATTN_QG(f16); else D3PM_ATTN_QG(bf16);
 #undef D3PM_ATTN_QG
 #undef D3PM_ATTN
   D3PM_LAUNCH_CHECK();

@@ -380,9 +380,19 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_gemm_persist_slots(int v) { g_persist_slots = v; }
 
 bool panel64_linear_supported(int dtype, const LinearArgs& a);
-int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s);
+bool panel64_ln_supported(int dtype, const LinearArgs& a, const LnPrologue& ln);
+int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s, const LnPrologue* ln = nullptr);
 int big_linear_tile(int dtype, const LinearArgs& a, int want);
 int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s);
+
+// The LayerNorm-prologue form exists for the latency schedule only: true where mfma_linear would pick that schedule anyway
+bool ln_prologue_linear_applies(int dtype, const LinearArgs& a, const LnPrologue& ln) {
+  const bool autosel = g_gemm_variant == 0;
+  if (!(g_gemm_variant == 4 || (autosel && a.M <= 1536))) return false;
+  if (autosel && big_linear_tile(dtype, a, 0)) return false;
+  return panel64_ln_supported(dtype, a, ln);
+}
+int ln_prologue_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, hipStream_t s) { return panel64_linear(dtype, a, s, &ln); }
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   // All schedules accumulate in the same order, so the choice never changes a bit of the result.

@@ -15,6 +15,12 @@
 //   * within a round the four k-steps run back to back, no barriers (the whole round has landed);
 //   * same swizzled 128-byte-row LDS image per 64-k sub-tile, same D = W_frag . X_frag^T orientation, same k order
 //     and the same epilogue code as the other schedules: bit-identical results.
+//   * LayerNorm prologue (LNPRO, K = d_model = 512): the projections fed by a LayerNorm (ar_discrete.py:131-132 norm1 -> qkv,
+//     :136-142 norm2 | norm22 -> the cross-attention queries, :145-159 norm3 + FiLM -> fc1) take the RESIDUAL STREAM as their
+//     operand: the tile's 64 whole rows are in LDS anyway, so each wave normalises 16 of them in place -- lane L owns the
+//     8-element chunk L of a row, exactly layernorm_vec's layout, same arithmetic and reduction order, same bits -- before the
+//     MFMAs start.  Every column tile of a row block redoes the rows' LayerNorm (8 .. 32 x redundant, ~1 us), which at one
+//     utterance is far cheaper than the separate launch it removes: 18 of the 67 launches of a diffusion iteration.
 #include "d3pm_kernels.h"
 #include "d3pm_mfma_tile.h"
 
@@ -32,12 +38,16 @@ __device__ __forceinline__ int xcd_remap_lat(int bid, int nblocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <typename T, int EPI>
+template <typename T> struct LnProArgs {
+  const T* w; const T* b; const T* w2; const T* b2; const T* film; float eps; int period;
+};
+
+template <typename T, int EPI, bool LNPRO = false>
 __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                             const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                             const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                             int mask_period, int M, int N, int K, int n_tiles,
-                                                            const uint16_t* __restrict__ gelu_tab_g) {
+                                                            const uint16_t* __restrict__ gelu_tab_g, LnProArgs<T> ln) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,6 +74,9 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
     int mr = m0 + row, nr = n0 + row;
     mr = mr < M ? mr : M - 1;                // ragged edges: clamped loads, predicated stores
     nr = nr < N ? nr : N - 1;
+    if constexpr (LNPRO) {
+      if (ln.period) mr %= ln.period;        // rows >= period: the same source rows under the second LayerNorm (norm2 | norm22)
+    }
     gx[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
     gw[i] = W + static_cast<size_t>(nr) * K + logical * 8;
   }
@@ -87,11 +100,49 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
   const int rounds = K / KC;                 // K is a multiple of 256 (launcher)
   issue_round(0, 0);
   if (rounds > 1) issue_round(1, 1);
+  if constexpr (LNPRO) {                     // K = 512: both rounds are the whole rows
+    const bool second = ln.period && m0 >= ln.period;
+    const T* lw = second ? ln.w2 : ln.w;
+    const T* lb = second ? ln.b2 : ln.b;
+    const Pack8<T> wv = *reinterpret_cast<const Pack8<T>*>(lw + lane * 8), bv = *reinterpret_cast<const Pack8<T>*>(lb + lane * 8);
+    Pack8<T> sc, sh;
+    if (ln.film) { sc = *reinterpret_cast<const Pack8<T>*>(ln.film + lane * 8); sh = *reinterpret_cast<const Pack8<T>*>(ln.film + 512 + lane * 8); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // every wave's pieces of both rounds have landed
+    // chunk c = lane of a row: round c >> 5, sub-tile (c >> 3) & 3, 16-byte chunk c & 7 of the swizzled 128-byte row
+    char* const chunk_base = smem + (lane >> 5) * BUF_BYTES + ((lane >> 3) & 3) * SUB_BYTES;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int row = wave * 16 + i;
+      Pack8<T>* px = reinterpret_cast<Pack8<T>*>(chunk_base + lds_off(row, lane & 7));
+      const Pack8<T> raw = *px;
+      float v[8], sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[e] = static_cast<float>(raw.v[e]); sum += v[e]; }
+      const float mean = wave_sum_up(sum) / 512.0f;
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; q += t * t; }
+      const float rstd = rsqrtf(wave_sum_up(q) / 512.0f + ln.eps);
+      Pack8<T> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.v[e] = static_cast<T>((v[e] - mean) * rstd * static_cast<float>(wv.v[e]) + static_cast<float>(bv.v[e]));
+      if (ln.film) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gg = rn<T>(1.0f + static_cast<float>(sc.v[e]));
+          o.v[e] = static_cast<T>(rn<T>(static_cast<float>(o.v[e]) * gg) + static_cast<float>(sh.v[e]));
+        }
+      }
+      *px = o;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   for (int r = 0; r < rounds; ++r) {
     const int buf = r & 1;
     if (r + 1 < rounds) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the next round's 16 pieces may stay in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // every wave's pieces of round r have landed
+    __builtin_amdgcn_s_barrier();            // every wave's pieces of round r have landed (LNPRO: and every row is normalised)
     __builtin_amdgcn_sched_barrier(0);
     const char* bx = smem + buf * BUF_BYTES;
     const char* bw = bx + OPER_BYTES;
@@ -141,7 +192,15 @@ bool panel64_linear_supported(int dtype, const LinearArgs& a) {
 const uint16_t* gelu_table_device(hipStream_t s);
 int gelu_table_enabled();
 
-int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s) {
+// the LayerNorm-prologue form: X is the un-normalised residual stream [period or M][512]
+bool panel64_ln_supported(int dtype, const LinearArgs& a, const LnPrologue& ln) {
+  if (!panel64_linear_supported(dtype, a) || a.K != 512 || a.R1 || a.row_mask || !ln.w || !ln.b) return false;
+  if ((ln.w2 != nullptr) != (ln.b2 != nullptr) || (ln.w2 != nullptr) != (ln.period > 0)) return false;
+  if (ln.period && (ln.period % LT != 0 || a.M != 2 * ln.period || ln.film)) return false;
+  return aligned16l(ln.w) && aligned16l(ln.b) && aligned16l(ln.w2) && aligned16l(ln.b2) && aligned16l(ln.film);
+}
+
+int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s, const LnPrologue* lnp) {
   const uint16_t* tab = (a.act == ACT_GELU && dtype == D3PM_BF16 && gelu_table_enabled()) ? gelu_table_device(s) : nullptr;
   const size_t lds = 2 * BUF_BYTES + (tab ? GELU_TAB_BYTES : 0);
   const int n_tiles = (a.N + LT - 1) / LT, m_tiles = (a.M + LT - 1) / LT;
@@ -157,11 +216,33 @@ int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s) {
     }                                                                                                                   \
     gemm_mfma_panel64<U, E><<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), \
         static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy, static_cast<const U*>(a.R1),                       \
-        static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles, tab);                    \
+        static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles, tab, LnProArgs<U>{});   \
+    return D3PM_OK;                                                                                                     \
+  } while (0)
+#define D3PM_LAT_LN(E)                                                                                                  \
+  do {                                                                                                                  \
+    static bool attr_set = false;                                                                                       \
+    if (!attr_set) {                                                                                                    \
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_panel64<U, E, true>),                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + GELU_TAB_BYTES));  \
+      attr_set = true;                                                                                                  \
+    }                                                                                                                   \
+    const LnProArgs<U> la{static_cast<const U*>(lnp->w), static_cast<const U*>(lnp->b), static_cast<const U*>(lnp->w2),  \
+                          static_cast<const U*>(lnp->b2), static_cast<const U*>(lnp->film), lnp->eps, lnp->period};      \
+    gemm_mfma_panel64<U, E, true><<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), \
+        static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy, nullptr, nullptr, a.ldr, nullptr, 1, a.M, a.N, a.K,  \
+        n_tiles, tab, la);                                                                                              \
     return D3PM_OK;                                                                                                     \
   } while (0)
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
+    if (lnp) {
+      switch (epi) {
+        case 0: D3PM_LAT_LN(0);
+        case EPI_GELU: D3PM_LAT_LN(EPI_GELU);
+        default: return D3PM_E_SHAPE;
+      }
+    }
     switch (epi) {
       case 0: D3PM_LAT(0);
       case EPI_GELU: D3PM_LAT(EPI_GELU);
@@ -173,6 +254,7 @@ int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s) {
     return D3PM_E_SHAPE;
   };
 #undef D3PM_LAT
+#undef D3PM_LAT_LN
   int rc = dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
   if (rc != D3PM_OK) return rc;
   D3PM_LAUNCH_CHECK();

@@ -134,6 +134,8 @@ SIGNATURES = {
                                     C.c_void_p]),
     "d3pm_op_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_float, C.c_void_p]),
+    "d3pm_op_linear_lnpro": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "d3pm_op_linear_rowpanel": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
@@ -600,6 +602,19 @@ def op_layernorm(x, w, b, film=None, eps=1e-6):
     return y
 
 
+def op_linear_lnpro(x, w, bias, ln_w, ln_b, *, ln2_w=None, ln2_b=None, film=None, act=0, eps=1e-6):
+    """act(LN(x) @ w.T + bias) in one launch of the latency GEMM; x [m, 512] is the un-normalised stream.  With a second
+    LayerNorm the result has 2 m rows (x under ln, then x under ln2)."""
+    m = x.shape[0]
+    if not (x.shape[1] == 512 and w.shape[1] == 512 and x.is_contiguous() and w.is_contiguous()):
+        raise ValueError("op_linear_lnpro: x [m,512], w [N,512], contiguous")
+    M, N = (2 * m if ln2_w is not None else m), w.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(lib().d3pm_op_linear_lnpro(dtype_code(x.dtype), _p(x), _p(w), _p(bias), _p(y), M, N, act, _p(ln_w), _p(ln_b), _p(ln2_w),
+                                     _p(ln2_b), _p(film), eps, stream_ptr()), "d3pm_op_linear_lnpro")
+    return y
+
+
 def op_linear_rowpanel(x, w, bias, r1, ln_w, ln_b, *, x2=None, ln2_w=None, ln2_b=None, film=None, row_mask=None, eps=1e-6):
     """Projection onto the residual stream + the LayerNorm(s) of the new rows in one launch (include/d3pm_hip.h).
     Returns (y, ln_y, ln2_y | None)."""
@@ -675,6 +690,10 @@ def set_attn_query_groups(v: int):
 
 def set_attn_pair_sequential(v: bool):
     check(lib().d3pm_set_tuning(3, 1 if v else 0), "d3pm_set_tuning")
+
+
+def set_ln_prologue(v: bool):
+    check(lib().d3pm_set_tuning(9, 1 if v else 0), "d3pm_set_tuning")
 
 
 def set_row_panel(mask: int):
