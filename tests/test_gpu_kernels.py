@@ -495,3 +495,40 @@ def test_generate_audio_is_the_same_with_and_without_layernorm_prologues(built_l
         finally:
             _hip.set_ln_prologue(True)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("epi,M,N,K", [("bias", 768, 1536, 512), ("gelu", 768, 2048, 512), ("r1", 768, 512, 512), ("r1r2", 768, 512, 512),
+                                       ("r1mask", 768, 512, 2048), ("bias", 750, 1025, 512), ("gelu", 100, 2048, 256), ("r1mask", 1500, 512, 1024)])
+def test_latency_gemm_tile_geometries_are_bit_identical(built_lib, dtype, epi, M, N, K):
+    """D3PM_TUNE_LAT_TILE: the 64 x 64, 96 x 64 and 32 x 64 tiles of the latency GEMM against the one-tile 128 x 128 kernel (same k
+    order, same epilogue code), whole and ragged shapes."""
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dtype).to(DEV)
+    x, w, b = mk(M, K), mk(N, K, sc=1.0 / math.sqrt(K)), mk(N, sc=0.3)
+    kw = {}
+    if epi == "gelu":
+        kw["act"] = 1
+    if epi in ("r1", "r1r2", "r1mask"):
+        kw["r1"] = mk(M, N)
+    if epi == "r1r2":
+        kw["r2"] = mk(M, N)
+    if epi == "r1mask":
+        kw["row_mask"] = (torch.rand(250, generator=g) < 0.9).to(torch.uint8).to(DEV)
+        kw["mask_period"] = 250
+    if N % 8:
+        kw["ldy"] = (N + 7) & ~7             # the final projection's padded logits rows
+    outs = []
+    try:
+        _hip.set_gemm_variant(5)
+        outs.append(_hip.op_linear(x, w, b, family=_hip.FAMILY_MFMA, **kw).clone())
+        _hip.set_gemm_variant(4)
+        for tile in (1, 2, 3, 0):
+            _hip.set_lat_tile(tile)
+            outs.append(_hip.op_linear(x, w, b, family=_hip.FAMILY_MFMA, **kw).clone())
+    finally:
+        _hip.set_gemm_variant(0)
+        _hip.set_lat_tile(0)
+    for i, o in enumerate(outs[1:]):
+        assert torch.equal(outs[0], o), f"lat tile arm {i}: {(outs[0] != o).sum().item()} elements differ"

@@ -29,6 +29,7 @@ void set_gemm_variant(int v);
 void set_gemm_persist_slots(int v);
 void set_attn_pair_sequential(int v);
 void set_attn_qg(int v);
+void set_lat_tile(int v);
 void set_attn_cross_resident(int v);
 void set_gelu_table(int v);
 void set_big_gemm_mode(int v);
@@ -838,6 +839,7 @@ int d3pm_set_tuning(int knob, int value) {
   if (knob == D3PM_TUNE_GELU_TABLE && (value == 0 || value == 1)) { set_gelu_table(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_CROSS_RESIDENT && (value == 0 || value == 1)) { set_attn_cross_resident(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_FUSED_FINAL_SAMPLE && (value == 0 || value == 1)) { g_fused_final_sample = value; return D3PM_OK; }
+  if (knob == D3PM_TUNE_LAT_TILE && value >= 0 && value <= 3) { set_lat_tile(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_LN_PROLOGUE && (value == 0 || value == 1)) { g_ln_prologue = value; return D3PM_OK; }
   if (knob == D3PM_TUNE_ROW_PANEL && value >= 0 && value <= 7) { g_row_panel = value; return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_PERSIST_SLOTS && value >= 8 && value <= 4096 && value % 8 == 0) { set_gemm_persist_slots(value); return D3PM_OK; }

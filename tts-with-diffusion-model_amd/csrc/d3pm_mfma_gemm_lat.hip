@@ -27,11 +27,18 @@
 namespace d3pm {
 namespace {
 
-constexpr int LT = 64;                       // tile rows and columns
+constexpr int LT = 64;                       // tile rows and columns of the base geometry
 constexpr int KC = 256;                      // k per round
-constexpr int SUB_BYTES = LT * ROW_BYTES;    // one [64][64 k] sub-tile: 8 KiB
-constexpr int OPER_BYTES = (KC / BK) * SUB_BYTES;   // one operand of a round: 32 KiB
-constexpr int BUF_BYTES = 2 * OPER_BYTES;    // X + W of a round: 64 KiB
+// Tile geometries (TM x TN, four waves as 2 x 2): 64 x 64 is the base; 96 x 64 turns the 288 / 384 tiles of the qkv / fc1
+// projections of one utterance (two rounds over 256 CUs at one workgroup per CU) into 192 / 256 (one round, one DMA flight);
+// 32 x 64 gives the N = 512 projections (out-proj, fc2: 96 tiles of 64 x 64) 192 workgroups with half the X panel each.
+template <int TM, int TN> struct LatGeom {
+  static constexpr int XSUB = TM * ROW_BYTES, WSUB = TN * ROW_BYTES;     // one [rows][64 k] sub-tile of each operand
+  static constexpr int XOPER = (KC / BK) * XSUB, WOPER = (KC / BK) * WSUB;
+  static constexpr int BUF = XOPER + WOPER;                              // X + W of a round
+};
+constexpr int BUF_BYTES = LatGeom<64, 64>::BUF;     // 64 KiB (the LayerNorm prologue runs on the base geometry)
+constexpr int SUB_BYTES = LatGeom<64, 64>::XSUB;
 
 __device__ __forceinline__ int xcd_remap_lat(int bid, int nblocks) {
   const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
@@ -42,60 +49,68 @@ template <typename T> struct LnProArgs {
   const T* w; const T* b; const T* w2; const T* b2; const T* film; float eps; int period;
 };
 
-template <typename T, int EPI, bool LNPRO = false>
+template <typename T, int EPI, bool LNPRO = false, int TM = 64, int TN = 64>
 __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                             const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                             const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                             int mask_period, int M, int N, int K, int n_tiles,
                                                             const uint16_t* __restrict__ gelu_tab_g, LnProArgs<T> ln) {
+  using G = LatGeom<TM, TN>;
+  static_assert(!LNPRO || (TM == 64 && TN == 64), "the LayerNorm prologue is written for the base geometry");
+  static_assert(TM % 32 == 0 && TN % 64 == 0, "four waves as 2 x 2, column blocks regrouped in pairs");
+  constexpr int XP = TM / 32, WP = TN / 32;       // DMA pieces (8 rows) per wave and sub-tile = MFMA row / column blocks per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const uint16_t* gelu_tab = nullptr;
-  if constexpr ((EPI & EPI_GELU) != 0 && std::is_same<T, bf16>::value) {
+  if constexpr ((EPI & EPI_GELU) != 0 && std::is_same<T, bf16>::value && 2 * G::BUF + GELU_TAB_BYTES <= 160 * 1024) {
     if (gelu_tab_g) {                       // bf16 GELU by table lookup (d3pm_mfma_tile.h); published by the first barrier
-      gelu_table_to_lds(gelu_tab_g, smem + 2 * BUF_BYTES, tid, 256);
-      gelu_tab = reinterpret_cast<const uint16_t*>(smem + 2 * BUF_BYTES);
+      gelu_table_to_lds(gelu_tab_g, smem + 2 * G::BUF, tid, 256);
+      gelu_tab = reinterpret_cast<const uint16_t*>(smem + 2 * G::BUF);
     }
   }
   const int bid = xcd_remap_lat(blockIdx.x, gridDim.x);
-  const int m0 = (bid / n_tiles) * LT, n0 = (bid % n_tiles) * LT;
+  const int m0 = (bid / n_tiles) * TM, n0 = (bid % n_tiles) * TN;
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
-  // DMA piece (sub-tile s, rows 8j .. 8j+7): a wave takes j = wave and wave + 4 of every sub-tile of both operands
-  // (swizzle key (row >> 1) & 7 = (4 (j & 1) + (lane >> 4)) & 7: two parities -> two per-lane offsets per operand)
+  // DMA piece (sub-tile s, rows 8j .. 8j+7): a wave takes the pieces j = wave + 4 i of every sub-tile of both operands
+  // (swizzle key (row >> 1) & 7: one per-lane offset per piece)
   const int lrow = lane >> 3;
-  const T* gx[2];
-  const T* gw[2];
+  const T* gx[XP];
+  const T* gw[WP];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int j = wave + 4 * i, row = 8 * j + lrow;
-    const int logical = (lane & 7) ^ ((row >> 1) & 7);
-    int mr = m0 + row, nr = n0 + row;
+  for (int i = 0; i < XP; ++i) {
+    const int row = 8 * (wave + 4 * i) + lrow;
+    int mr = m0 + row;
     mr = mr < M ? mr : M - 1;                // ragged edges: clamped loads, predicated stores
-    nr = nr < N ? nr : N - 1;
     if constexpr (LNPRO) {
       if (ln.period) mr %= ln.period;        // rows >= period: the same source rows under the second LayerNorm (norm2 | norm22)
     }
-    gx[i] = X + static_cast<size_t>(mr) * ldx + logical * 8;
-    gw[i] = W + static_cast<size_t>(nr) * K + logical * 8;
+    gx[i] = X + static_cast<size_t>(mr) * ldx + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
   }
-  auto issue_round = [&](int r, int buf) {   // 16 pieces per wave
-    const uint32_t base = lds_base + buf * BUF_BYTES;
 #pragma unroll
-    for (int s = 0; s < KC / BK; ++s)
+  for (int i = 0; i < WP; ++i) {
+    const int row = 8 * (wave + 4 * i) + lrow;
+    int nr = n0 + row;
+    nr = nr < N ? nr : N - 1;
+    gw[i] = W + static_cast<size_t>(nr) * K + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  constexpr int PIECES = (KC / BK) * (XP + WP);       // per wave and round
+  auto issue_round = [&](int r, int buf) {
+    const uint32_t base = lds_base + buf * G::BUF;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int j = wave + 4 * i;
-        glds16_asm(gx[i] + r * KC + s * BK, base + s * SUB_BYTES + j * 1024);
-        glds16_asm(gw[i] + r * KC + s * BK, base + OPER_BYTES + s * SUB_BYTES + j * 1024);
-      }
+    for (int s = 0; s < KC / BK; ++s) {
+#pragma unroll
+      for (int i = 0; i < XP; ++i) glds16_asm(gx[i] + r * KC + s * BK, base + s * G::XSUB + (wave + 4 * i) * 1024);
+#pragma unroll
+      for (int i = 0; i < WP; ++i) glds16_asm(gw[i] + r * KC + s * BK, base + G::XOPER + s * G::WSUB + (wave + 4 * i) * 1024);
+    }
   };
-  floatx4 acc[2][2];
+  floatx4 acc[WP][XP];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < WP; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < XP; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15, fch = lane >> 4;
   const int rounds = K / KC;                 // K is a multiple of 256 (launcher)
   issue_round(0, 0);
@@ -140,26 +155,25 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
   }
   for (int r = 0; r < rounds; ++r) {
     const int buf = r & 1;
-    if (r + 1 < rounds) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the next round's 16 pieces may stay in flight
+    if (r + 1 < rounds) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");   // the next round's pieces may stay in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // every wave's pieces of round r have landed (LNPRO: and every row is normalised)
     __builtin_amdgcn_sched_barrier(0);
-    const char* bx = smem + buf * BUF_BYTES;
-    const char* bw = bx + OPER_BYTES;
+    const char* bx = smem + buf * G::BUF;
+    const char* bw = bx + G::XOPER;
 #pragma unroll
     for (int s = 0; s < KC / BK; ++s)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        uint4 fx[2], fw[2];
+        uint4 fx[XP], fw[WP];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          fx[q] = *reinterpret_cast<const uint4*>(bx + s * SUB_BYTES + lds_off(wm * 32 + q * 16 + frow, ks * 4 + fch));
-          fw[q] = *reinterpret_cast<const uint4*>(bw + s * SUB_BYTES + lds_off(wn * 32 + q * 16 + frow, ks * 4 + fch));
-        }
+        for (int q = 0; q < XP; ++q) fx[q] = *reinterpret_cast<const uint4*>(bx + s * G::XSUB + lds_off(wm * (TM / 2) + q * 16 + frow, ks * 4 + fch));
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int q = 0; q < WP; ++q) fw[q] = *reinterpret_cast<const uint4*>(bw + s * G::WSUB + lds_off(wn * (TN / 2) + q * 16 + frow, ks * 4 + fch));
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
+        for (int nt = 0; nt < WP; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < XP; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
       }
     __builtin_amdgcn_sched_barrier(0);
     if (r + 2 < rounds) {
@@ -168,8 +182,8 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
       issue_round(r + 2, buf);
     }
   }
-  epilogue_store<T, EPI, 2, 2>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 32, n0 + wn * 32, lane, nullptr,
-                               gelu_tab);
+  epilogue_store<T, EPI, WP, XP>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * (TM / 2), n0 + wn * (TN / 2), lane,
+                                 nullptr, gelu_tab);
 }
 
 inline bool aligned16l(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
@@ -200,65 +214,77 @@ bool panel64_ln_supported(int dtype, const LinearArgs& a, const LnPrologue& ln) 
   return aligned16l(ln.w) && aligned16l(ln.b) && aligned16l(ln.w2) && aligned16l(ln.b2) && aligned16l(ln.film);
 }
 
+// D3PM_TUNE_LAT_TILE: 0 auto, 1 / 2 / 3 = always 64 x 64 / 96 x 64 / 32 x 64.  Auto: the geometry with the fewest rounds over the
+// 256 CUs (one workgroup per CU), then the one with the most workgroups (the time of a launch here is the latency of one
+// workgroup's chain -- DMA flight, k-steps, epilogue -- so a round less or a shorter chain is what pays; flops do not matter)
+static int g_lat_tile = 0;
+void set_lat_tile(int v) { g_lat_tile = v; }
+static int lat_geometry(const LinearArgs& a) {
+  if (g_lat_tile >= 1 && g_lat_tile <= 3) return g_lat_tile - 1;
+  static const int tm[3] = {64, 96, 32};
+  int best = 0;
+  long long best_rounds = 0, best_tiles = 0;
+  for (int g = 0; g < 3; ++g) {
+    const long long tiles = static_cast<long long>((a.M + tm[g] - 1) / tm[g]) * ((a.N + 63) / 64), rounds = (tiles + 255) / 256;
+    if (g == 0 || rounds < best_rounds || (rounds == best_rounds && tiles > best_tiles)) { best = g; best_rounds = rounds; best_tiles = tiles; }
+  }
+  return best;
+}
+
+template <typename U, int E, bool LN, int TM, int TN>
+static int panel64_launch(const LinearArgs& a, const LnPrologue* lnp, const uint16_t* tab, hipStream_t s) {
+  using G = LatGeom<TM, TN>;
+  constexpr size_t kMaxLds = 2 * G::BUF + GELU_TAB_BYTES <= 160 * 1024 ? 2 * G::BUF + GELU_TAB_BYTES : 2 * G::BUF;
+  if (2 * G::BUF + GELU_TAB_BYTES > 160 * 1024) tab = nullptr;            // no room for the table beside this geometry's panels
+  const size_t lds = 2 * G::BUF + (tab ? GELU_TAB_BYTES : 0);
+  const int n_tiles = (a.N + TN - 1) / TN, m_tiles = (a.M + TM - 1) / TM;
+  static bool attr_set = false;
+  if (!attr_set) {
+    D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_panel64<U, E, LN, TM, TN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    attr_set = true;
+  }
+  LnProArgs<U> la{};
+  if (lnp) la = LnProArgs<U>{static_cast<const U*>(lnp->w), static_cast<const U*>(lnp->b), static_cast<const U*>(lnp->w2),
+                             static_cast<const U*>(lnp->b2), static_cast<const U*>(lnp->film), lnp->eps, lnp->period};
+  gemm_mfma_panel64<U, E, LN, TM, TN><<<dim3(static_cast<unsigned>(n_tiles * m_tiles)), dim3(256), lds, s>>>(
+      static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
+      static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles, tab, la);
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+template <typename U, int E> static int panel64_geometry(const LinearArgs& a, const uint16_t* tab, hipStream_t s) {
+  switch (lat_geometry(a)) {
+    case 1: return panel64_launch<U, E, false, 96, 64>(a, nullptr, tab, s);
+    case 2: return panel64_launch<U, E, false, 32, 64>(a, nullptr, tab, s);
+    default: return panel64_launch<U, E, false, 64, 64>(a, nullptr, tab, s);
+  }
+}
+
 int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s, const LnPrologue* lnp) {
   const uint16_t* tab = (a.act == ACT_GELU && dtype == D3PM_BF16 && gelu_table_enabled()) ? gelu_table_device(s) : nullptr;
-  const size_t lds = 2 * BUF_BYTES + (tab ? GELU_TAB_BYTES : 0);
-  const int n_tiles = (a.N + LT - 1) / LT, m_tiles = (a.M + LT - 1) / LT;
-  const dim3 grid(static_cast<unsigned>(n_tiles * m_tiles)), block(256);
   const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
-#define D3PM_LAT(E)                                                                                                     \
-  do {                                                                                                                  \
-    static bool attr_set = false;                                                                                       \
-    if (!attr_set) {                                                                                                    \
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_panel64<U, E>),                       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + GELU_TAB_BYTES));  \
-      attr_set = true;                                                                                                  \
-    }                                                                                                                   \
-    gemm_mfma_panel64<U, E><<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), \
-        static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy, static_cast<const U*>(a.R1),                       \
-        static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles, tab, LnProArgs<U>{});   \
-    return D3PM_OK;                                                                                                     \
-  } while (0)
-#define D3PM_LAT_LN(E)                                                                                                  \
-  do {                                                                                                                  \
-    static bool attr_set = false;                                                                                       \
-    if (!attr_set) {                                                                                                    \
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_panel64<U, E, true>),                 \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + GELU_TAB_BYTES));  \
-      attr_set = true;                                                                                                  \
-    }                                                                                                                   \
-    const LnProArgs<U> la{static_cast<const U*>(lnp->w), static_cast<const U*>(lnp->b), static_cast<const U*>(lnp->w2),  \
-                          static_cast<const U*>(lnp->b2), static_cast<const U*>(lnp->film), lnp->eps, lnp->period};      \
-    gemm_mfma_panel64<U, E, true><<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), \
-        static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy, nullptr, nullptr, a.ldr, nullptr, 1, a.M, a.N, a.K,  \
-        n_tiles, tab, la);                                                                                              \
-    return D3PM_OK;                                                                                                     \
-  } while (0)
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
     if (lnp) {
       switch (epi) {
-        case 0: D3PM_LAT_LN(0);
-        case EPI_GELU: D3PM_LAT_LN(EPI_GELU);
+        case 0: return panel64_launch<U, 0, true, 64, 64>(a, lnp, tab, s);
+        case EPI_GELU: return panel64_launch<U, EPI_GELU, true, 64, 64>(a, lnp, tab, s);
         default: return D3PM_E_SHAPE;
       }
     }
     switch (epi) {
-      case 0: D3PM_LAT(0);
-      case EPI_GELU: D3PM_LAT(EPI_GELU);
-      case EPI_R1: D3PM_LAT(EPI_R1);
-      case EPI_R2: D3PM_LAT(EPI_R2);
-      case EPI_R1 | EPI_MASK: D3PM_LAT(EPI_R1 | EPI_MASK);
+      case 0: return panel64_geometry<U, 0>(a, tab, s);
+      case EPI_GELU: return panel64_geometry<U, EPI_GELU>(a, tab, s);
+      case EPI_R1: return panel64_geometry<U, EPI_R1>(a, tab, s);
+      case EPI_R2: return panel64_geometry<U, EPI_R2>(a, tab, s);
+      case EPI_R1 | EPI_MASK: return panel64_geometry<U, EPI_R1 | EPI_MASK>(a, tab, s);
       default: break;
     }
     return D3PM_E_SHAPE;
   };
-#undef D3PM_LAT
-#undef D3PM_LAT_LN
-  int rc = dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
-  if (rc != D3PM_OK) return rc;
-  D3PM_LAUNCH_CHECK();
-  return D3PM_OK;
+  return dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
 }
 
 }  // namespace d3pm

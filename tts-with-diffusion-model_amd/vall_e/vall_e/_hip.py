@@ -692,6 +692,10 @@ def set_attn_pair_sequential(v: bool):
     check(lib().d3pm_set_tuning(3, 1 if v else 0), "d3pm_set_tuning")
 
 
+def set_lat_tile(v: int):
+    check(lib().d3pm_set_tuning(10, int(v)), "d3pm_set_tuning")
+
+
 def set_ln_prologue(v: bool):
     check(lib().d3pm_set_tuning(9, 1 if v else 0), "d3pm_set_tuning")
 
