@@ -341,16 +341,18 @@ int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, c
  *                         Results are bit-identical across schedules.
  * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention: 0 = auto (default: 2 when that still
  *                         gives >= 4 workgroups per CU, else 1), 1 or 2.
- * D3PM_TUNE_ATTN_PAIR_SEQUENTIAL: 1 (default) = a paired attention launch (text + prompt cross-attention) runs both
- *                         problems in every workgroup, one after the other; 0 = the second half of the grid takes problem 2.
+ * D3PM_TUNE_ATTN_PAIR_SEQUENTIAL: a paired attention launch (text + prompt cross-attention) on the tile-by-tile kernel: 2 = every
+ *                         workgroup runs both problems, one after the other; 0 = the second half of the grid takes problem 2;
+ *                         1 (default) = auto: sequential while that still leaves >= 2 workgroups per CU.
  * D3PM_TUNE_GEMM_PERSIST_SLOTS: resident workgroups of the persistent throughput schedule, a multiple of 8
  *                         (default 1024 = 4 per CU).
  * D3PM_TUNE_GELU_TABLE:   1 = the bf16 GELU epilogue of the 192 x 256 big-tile and the latency GEMM reads rn_bf16(gelu(v)) from
  *                         an 8.5 KiB LDS table filled on the device by the arithmetic path itself (bit-identical results);
  *                         0 (default: the table measured slower, 86 vs 73 us on fc1) = always the arithmetic path.
- * D3PM_TUNE_ATTN_CROSS_RESIDENT: 1 (default) = the text + prompt cross-attention pair of a block (<= 64 and <= 256 keys) runs
- *                         with every K / V tile of both problems fetched into LDS at kernel entry (one wait, no per-tile
- *                         barrier, 256 queries per workgroup); 0 = the tile-by-tile kernel.  Same results.
+ * D3PM_TUNE_ATTN_CROSS_RESIDENT: the text + prompt cross-attention pair of a block (<= 64 and <= 256 keys) with every K / V tile of
+ *                         both problems fetched into LDS at kernel entry (one wait, no per-tile barrier, 256 queries per
+ *                         workgroup): 2 = always, 0 = never (tile-by-tile kernel), 1 (default) = auto: when that grid has at
+ *                         least one workgroup per CU (batch >= 11 at 768 rows and 8 heads).  Same results.
  * D3PM_TUNE_FUSED_FINAL_SAMPLE: 1 = inside d3pm_sample_loop the final projection, the posterior and the draw are one
  *                         kernel and the logits never reach HBM (16-bit model, d_model a multiple of 32, MFMA family);
  *                         0 (default: measured faster) = the two-launch form (final GEMM, then d3pm_posterior_sample's

@@ -8,7 +8,7 @@ texts, proms = synth.make_inputs(cfg, 32, 1)
 m.generate_audio(texts, proms, steps=5, seed=1)
 for rep in range(2):
     for mode in (1, 0):
-        _hip.set_attn_pair_sequential(bool(mode))
+        _hip.set_attn_pair_sequential(2 if mode else 0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = m.generate_audio(texts, proms, seed=3)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0

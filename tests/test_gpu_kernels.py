@@ -359,7 +359,7 @@ def test_cross_attention_pair_resident_kernel_equals_the_tile_by_tile_kernel(bui
             lg, hid = smp.denoise(x, fm, 30, kv_t, kv_p, want_hidden=True)
             outs.append((lg.clone(), hid.clone()))
     finally:
-        _hip.set_attn_cross_resident(True)
+        _hip.set_attn_cross_resident(1)
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
 
 

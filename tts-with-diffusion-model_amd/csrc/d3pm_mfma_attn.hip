@@ -493,15 +493,20 @@ bool mfma_attention_supported(int dtype, const AttnArgs& a) {
 // 768 x 768 x 256-head self-attention, 27.7 vs 30.1 us on the 225-key prompt attention) once that still leaves >= 4
 // workgroups per CU, one group otherwise (a single utterance is 48 workgroups of two groups: latency regime)
 static int g_attn_qg = 0;
-static bool g_attn_pair_seq = true;
+static int g_attn_pair_seq = 1;      // 0 never, 1 auto (when the paired grid still has >= 2 workgroups per CU), 2 always
 void set_attn_qg(int v) { g_attn_qg = v; }
-void set_attn_pair_sequential(int v) { g_attn_pair_seq = v != 0; }
+void set_attn_pair_sequential(int v) { g_attn_pair_seq = v; }
 
-static int g_attn_cross_resident = 1;   // cross-attention pair with every K / V tile resident in LDS (attn_cross_hd64)
+// cross-attention pair with every K / V tile resident in LDS (attn_cross_hd64): 0 never, 1 auto, 2 always.  Auto = when its
+// grid (256 queries per workgroup) has at least one workgroup per CU: at one utterance it is 24 workgroups of eight waves and
+// the tile-by-tile kernel's 192 small ones finish sooner (p50 latency 46.7 -> 42.2 ms, profiles/round2_d_latency_ab.txt)
+static int g_attn_cross_resident = 1;
 void set_attn_cross_resident(int v) { g_attn_cross_resident = v; }
 
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
-  if (g_attn_cross_resident && a.Q2 != nullptr && a.key_len == nullptr && a.S <= BKV && a.S2 <= 4 * BKV) {
+  const long long cross_wgs = static_cast<long long>((a.Tq + 255) / 256) * a.H * a.B;
+  if ((g_attn_cross_resident == 2 || (g_attn_cross_resident == 1 && cross_wgs >= 256)) && a.Q2 != nullptr && a.key_len == nullptr &&
+      a.S <= BKV && a.S2 <= 4 * BKV) {
     const int n_qblocks = (a.Tq + 255) / 256;
     const dim3 grid(static_cast<unsigned>(n_qblocks * a.H * a.B)), block(512);
     const size_t lds = static_cast<size_t>(1 + (a.S2 + BKV - 1) / BKV) * 2 * TILE;
@@ -526,7 +531,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
   const int qg = g_attn_qg == 0 ? (wgs2 >= 4 * 256 ? 2 : 1) : g_attn_qg >= 100 ? 2 : g_attn_qg, per_block = 64 * qg;
   const int n_qblocks = (a.Tq + per_block - 1) / per_block;
   const int n_blocks1 = n_qblocks * a.H * a.B;
-  const bool seq = a.Q2 != nullptr && g_attn_pair_seq;
+  const bool seq = a.Q2 != nullptr && (g_attn_pair_seq == 2 || (g_attn_pair_seq == 1 && n_blocks1 >= 512));
   const int n_first = seq ? -1 : n_blocks1;
   dim3 grid(static_cast<unsigned>(n_blocks1) * ((a.Q2 && !seq) ? 2 : 1)), block(256);
 #define D3PM_ATTN(T, QG, PAIR)                                                                                       \

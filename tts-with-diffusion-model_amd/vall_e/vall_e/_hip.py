@@ -688,8 +688,9 @@ def set_attn_query_groups(v: int):
     check(lib().d3pm_set_tuning(1, v), "d3pm_set_tuning")
 
 
-def set_attn_pair_sequential(v: bool):
-    check(lib().d3pm_set_tuning(3, 1 if v else 0), "d3pm_set_tuning")
+def set_attn_pair_sequential(v):
+    """0 / False never, 1 auto (default), 2 / True always."""
+    check(lib().d3pm_set_tuning(3, 2 if v is True else int(v)), "d3pm_set_tuning")
 
 
 def set_lat_tile(v: int):
@@ -708,8 +709,9 @@ def set_gelu_table(v: bool):
     check(lib().d3pm_set_tuning(7, 1 if v else 0), "d3pm_set_tuning")
 
 
-def set_attn_cross_resident(v: bool):
-    check(lib().d3pm_set_tuning(6, 1 if v else 0), "d3pm_set_tuning")
+def set_attn_cross_resident(v):
+    """0 / False never, 1 auto (default), 2 / True always."""
+    check(lib().d3pm_set_tuning(6, 2 if v is True else int(v)), "d3pm_set_tuning")
 
 
 def set_fused_final_sample(v: bool):
