@@ -350,9 +350,11 @@ int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, c
  *                         an 8.5 KiB LDS table filled on the device by the arithmetic path itself (bit-identical results);
  *                         0 (default: the table measured slower, 86 vs 73 us on fc1) = always the arithmetic path.
  * D3PM_TUNE_ATTN_CROSS_RESIDENT: the text + prompt cross-attention pair of a block (<= 64 and <= 256 keys) with every K / V tile of
- *                         both problems fetched into LDS at kernel entry (one wait, no per-tile barrier, 256 queries per
- *                         workgroup): 2 = always, 0 = never (tile-by-tile kernel), 1 (default) = auto: when that grid has at
- *                         least one workgroup per CU (batch >= 11 at 768 rows and 8 heads).  Same results.
+ *                         both problems fetched into LDS once per (utterance, head) -- one wait, no per-tile barrier -- by a
+ *                         workgroup of eight waves that then walks that head's 256-query blocks (the next block's queries
+ *                         prefetched): 2 = always, 0 = never (tile-by-tile kernel), 1 (default) = auto: when there is at least one
+ *                         such workgroup per CU (batch >= 11 at 768 rows and 8 heads); 3 = as 2 with one query block per
+ *                         workgroup (the first form, kept for A/B).  Same results.
  * D3PM_TUNE_FUSED_FINAL_SAMPLE: 1 = inside d3pm_sample_loop the final projection, the posterior and the draw are one
  *                         kernel and the logits never reach HBM (16-bit model, d_model a multiple of 32, MFMA family);
  *                         0 (default: measured faster) = the two-launch form (final GEMM, then d3pm_posterior_sample's
@@ -393,7 +395,8 @@ int d3pm_debug_gemm_clock(unsigned long long* clocks_and_ticks);
  * measure; launches outside the loop -- condition encoders, cond-K/V projections -- are never bracketed).
  * d3pm_prof_read_class synchronises the events of one class and returns its launch count, total milliseconds and the
  * algorithmic flops / bytes of those launches; d3pm_prof_read returns the sums over the classes and resets. */
-enum { D3PM_K_GEMM = 0, D3PM_K_ATTN = 1, D3PM_K_SAMPLE = 2, D3PM_K_LN = 3, D3PM_K_COUNT = 4 };
+/* D3PM_K_GEMM_LN: the launches that are a projection AND the LayerNorm(s) next to it (d3pm_op_linear_rowpanel / _lnpro) */
+enum { D3PM_K_GEMM = 0, D3PM_K_ATTN = 1, D3PM_K_SAMPLE = 2, D3PM_K_LN = 3, D3PM_K_GEMM_LN = 4, D3PM_K_COUNT = 5 };
 int d3pm_prof_enable(int kclass, int max_events);
 int d3pm_prof_read_class(int kclass, int *launches, double *total_ms, double *flops, double *bytes);
 int d3pm_prof_read(int *launches, double *total_ms, double *flops, double *bytes);

@@ -11,8 +11,31 @@ import glob
 import json
 import sys
 
-CLASSES = {"gemm": "gemm_mfma", "attention": "attn_mfma", "layernorm": "layernorm", "sample": "posterior_sample",
-           "embed": "embed_rows"}
+import re
+
+CLASSES = {"gemm": "gemm_mfma", "gemm_layernorm": "gemm_mfma_big", "attention": "attn_", "layernorm": "layernorm",
+           "sample": "posterior_sample", "embed": "embed_rows"}
+
+
+def fused_gemm(name):
+    """gemm_mfma_big<T, EPI, WM, WN, MODE, FUSE>: FUSE != 0 = the row-panel launches (projection + LayerNorms)."""
+    m = re.search(r"gemm_mfma_bigI\w+?Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EE", name)
+    if m:
+        return int(m.group(5)) != 0
+    m = re.search(r"gemm_mfma_big<([^>]*)>", name)
+    if m:
+        ints = re.findall(r"\b\d+\b", m.group(1))
+        return len(ints) >= 5 and int(ints[-1]) != 0
+    return False
+
+
+def classify(name):
+    if "gemm_mfma" in name:
+        return "gemm_layernorm" if fused_gemm(name) else "gemm"
+    for cls, needle in CLASSES.items():
+        if cls not in ("gemm", "gemm_layernorm") and needle in name:
+            return cls
+    return None
 
 
 def load(directory, counter):
@@ -22,10 +45,10 @@ def load(directory, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        for cls, needle in CLASSES.items():
-            if needle in r["Kernel_Name"]:
-                agg[cls][0] += 1
-                agg[cls][1] += float(r["Counter_Value"])
+        cls = classify(r["Kernel_Name"])
+        if cls:
+            agg[cls][0] += 1
+            agg[cls][1] += float(r["Counter_Value"])
     return agg
 
 

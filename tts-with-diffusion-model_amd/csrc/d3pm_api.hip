@@ -95,7 +95,7 @@ static int g_ln_prologue = 0;
 // LayerNorm + projection in one launch of the latency GEMM (d3pm_mfma_gemm_lat.hip); a.X is the un-normalised stream
 static int run_ln_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, hipStream_t s) {
   const size_t es = dtype_size(dtype);
-  ProfScope p(D3PM_K_GEMM, s, 2.0 * a.M * a.N * a.K,
+  ProfScope p(D3PM_K_GEMM_LN, s, 2.0 * a.M * a.N * a.K,
               es * (static_cast<double>(ln.period ? ln.period : a.M) * a.K + static_cast<double>(a.N) * a.K + static_cast<double>(a.M) * a.N));
   return ln_prologue_linear(dtype, a, ln, s);
 }
@@ -103,7 +103,7 @@ static int run_ln_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, h
 static int run_row_panel(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s) {
   const size_t es = dtype_size(dtype);
   const double prods = f.X2 ? 2.0 : 1.0, mn = static_cast<double>(a.M) * a.N;
-  ProfScope p(D3PM_K_GEMM, s, prods * 2.0 * a.M * a.N * a.K,
+  ProfScope p(D3PM_K_GEMM_LN, s, prods * 2.0 * a.M * a.N * a.K,
               es * (prods * a.M * a.K + static_cast<double>(a.N) * a.K + mn * (3.0 + (f.lny2 ? 1.0 : 0.0))));
   return row_panel_linear(dtype, a, f, s);
 }
@@ -837,7 +837,7 @@ int d3pm_set_tuning(int knob, int value) {
   if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && value >= 0 && value <= 2) { set_attn_pair_sequential(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 9 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465)) { set_big_gemm_mode(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GELU_TABLE && (value == 0 || value == 1)) { set_gelu_table(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_ATTN_CROSS_RESIDENT && value >= 0 && value <= 2) { set_attn_cross_resident(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_ATTN_CROSS_RESIDENT && value >= 0 && value <= 3) { set_attn_cross_resident(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_FUSED_FINAL_SAMPLE && (value == 0 || value == 1)) { g_fused_final_sample = value; return D3PM_OK; }
   if (knob == D3PM_TUNE_LAT_TILE && value >= 0 && value <= 3) { set_lat_tile(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_LN_PROLOGUE && (value == 0 || value == 1)) { g_ln_prologue = value; return D3PM_OK; }

@@ -134,15 +134,27 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
   const int r0s = tid >> 3, chs = tid & 7;
   const int ko0 = k_off(r0s, chs), ko1 = k_off(r0s + 32, chs), vo0 = v_off(r0s, chs), vo1 = v_off(r0s + 32, chs);
   struct Staged { uint4 k0, k1, v0, v1; };
+  // whole tiles: a wave-uniform tile base (scalar registers) + two per-lane byte offsets that never change, so a tile costs
+  // no vector address arithmetic; only a ragged last tile clamps its rows
+  const uint32_t lo0 = static_cast<uint32_t>(r0s * ldkv + chs * 8) * 2u, lo1 = lo0 + static_cast<uint32_t>(32 * ldkv) * 2u;
   auto load_tile = [=](int tile) -> Staged {
-    int a = tile * BKV + r0s, c = a + 32;
-    a = a < S ? a : S - 1;
-    c = c < S ? c : S - 1;
     Staged st;
-    st.k0 = *reinterpret_cast<const uint4*>(Kb + static_cast<size_t>(a) * ldkv + chs * 8);
-    st.k1 = *reinterpret_cast<const uint4*>(Kb + static_cast<size_t>(c) * ldkv + chs * 8);
-    st.v0 = *reinterpret_cast<const uint4*>(Vb + static_cast<size_t>(a) * ldkv + chs * 8);
-    st.v1 = *reinterpret_cast<const uint4*>(Vb + static_cast<size_t>(c) * ldkv + chs * 8);
+    const char* kt = reinterpret_cast<const char*>(Kb + static_cast<size_t>(tile) * BKV * ldkv);
+    const char* vt = reinterpret_cast<const char*>(Vb + static_cast<size_t>(tile) * BKV * ldkv);
+    if ((tile + 1) * BKV <= S) {
+      st.k0 = *reinterpret_cast<const uint4*>(kt + lo0);
+      st.k1 = *reinterpret_cast<const uint4*>(kt + lo1);
+      st.v0 = *reinterpret_cast<const uint4*>(vt + lo0);
+      st.v1 = *reinterpret_cast<const uint4*>(vt + lo1);
+    } else {
+      int a = tile * BKV + r0s, c = a + 32;
+      a = a < S ? a : S - 1;
+      c = c < S ? c : S - 1;
+      st.k0 = *reinterpret_cast<const uint4*>(Kb + static_cast<size_t>(a) * ldkv + chs * 8);
+      st.k1 = *reinterpret_cast<const uint4*>(Kb + static_cast<size_t>(c) * ldkv + chs * 8);
+      st.v0 = *reinterpret_cast<const uint4*>(Vb + static_cast<size_t>(a) * ldkv + chs * 8);
+      st.v1 = *reinterpret_cast<const uint4*>(Vb + static_cast<size_t>(c) * ldkv + chs * 8);
+    }
     return st;
   };
   auto store_tile = [=](char* base, const Staged& st) {
@@ -170,8 +182,22 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
     for (int dt = 0; dt < 4; ++dt) acc_o[qg][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int tile = 0; tile < n_tiles; ++tile) {
-    const char* kb = smem + (tile & 1) * 2 * TILE;
+  // per-lane LDS offsets of the fragment reads, computed once: the XOR swizzle only touches address bits that the tile-local
+  // row / column-block constants do not, so every read of a tile is one of these plus an instruction immediate
+  //   K (b128): row 16 kt + qi, chunk 4 ks + g          -> ok[ks] + kt * 2048
+  //   V (tr b64): row 32 kb2 + 16 half + 4 g + (qi >> 2), columns 16 dt + 4 (qi & 3) -> ov[dt] + kb2 * 4096 + half * 2048
+  int ok[2], ov[4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) ok[ks] = k_off(qi, ks * 4 + g);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int col = dt * 16 + 4 * (qi & 3);
+    ov[dt] = v_off(4 * g + (qi >> 2), col >> 3) + (col & 7) * 2;
+  }
+  // two tiles per trip so that the buffer a tile reads (and the one it fills) is a compile-time constant
+  auto do_tile = [&](int tile, auto BUF_) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(BUF_)::value;
+    const char* kb = smem + BUF * 2 * TILE;
     const char* vb = kb + TILE;
     const bool more = tile + 1 < n_tiles;
     if (more && !(ABL & 4)) st = load_tile(tile + 1);
@@ -188,22 +214,22 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
 #pragma unroll
           for (int qg = 0; qg < QG; ++qg) s[qg][kt] = negm[qg] + floatx4{0.1f * kt, 0.2f, 0.3f * tile, 0.4f};
         } else {
-        uint4 kf = *reinterpret_cast<const uint4*>(kb + k_off(kt * 16 + qi, ks * 4 + g));
+        uint4 kf = *reinterpret_cast<const uint4*>(kb + ok[ks] + kt * 16 * ROWB);
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) s[qg][kt] = mma<T>(kf, qf[qg][ks], ks == 0 ? negm[qg] : s[qg][kt]);
         }
       }
     // lane holds scores (log2 domain, minus m_ref) of its query for keys tile*64 + kt*16 + 4g + r
     const bool ragged = (tile == n_tiles - 1) && (S & (BKV - 1));   // wave-uniform: only the last tile can be partial
-    const int key_base = tile * BKV + 4 * g;
     uint4 pf[QG][2];
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
       if (ragged) {
+        const int lim = S - tile * BKV - 4 * g;              // keys of this lane's column that exist: compare with constants
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[qg][kt][r] = (key_base + kt * 16 + r < S) ? s[qg][kt][r] : -INFINITY;
+          for (int r = 0; r < 4; ++r) s[qg][kt][r] = (kt * 16 + r < lim) ? s[qg][kt][r] : -INFINITY;
       }
       float mx = fmaxf(s[qg][0][0], s[qg][0][1]);          // linear chain: hipcc folds pairs into v_max3_f32
       mx = fmaxf(fmaxf(mx, s[qg][0][2]), s[qg][0][3]);
@@ -262,11 +288,9 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         // 16-lane group g, lane qi: address of row (key0 + qi>>2), columns 16dt + 4(qi&3) .. +3
-        const int col = dt * 16 + 4 * (qi & 3);
-        const int r0 = (2 * kb2) * 16 + 4 * g + (qi >> 2), r1 = r0 + 16;
         typedef short4v __attribute__((address_space(3))) * lds_ptr;
-        short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + v_off(r0, col >> 3) + (col & 7) * 2));
-        short4v vc = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + v_off(r1, col >> 3) + (col & 7) * 2));
+        short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + ov[dt] + (2 * kb2) * 16 * ROWB));
+        short4v vc = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + ov[dt] + (2 * kb2 + 1) * 16 * ROWB));
         uint2 lo = __builtin_bit_cast(uint2, va), hi = __builtin_bit_cast(uint2, vc);
         const uint4 vf = uint4{lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
@@ -279,8 +303,12 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
 #pragma unroll
       for (int qg = 0; qg < QG; ++qg) acc_l[qg] = mma<T>(ones, pf[qg][kb2], acc_l[qg]);
     }
-    if (more && !(ABL & 4)) store_tile(smem + ((tile + 1) & 1) * 2 * TILE, st);
+    if (more && !(ABL & 4)) store_tile(smem + (BUF ^ 1) * 2 * TILE, st);
     if constexpr (!(ABL & 8)) __syncthreads();
+  };
+  for (int tile = 0; tile < n_tiles; tile += 2) {
+    do_tile(tile, std::integral_constant<int, 0>{});
+    if (tile + 1 < n_tiles) do_tile(tile + 1, std::integral_constant<int, 1>{});
   }
 
 #pragma unroll
@@ -314,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
                                                           T* __restrict__ O1, int S1, const T* __restrict__ Q2,
                                                           const T* __restrict__ K2, const T* __restrict__ V2, T* __restrict__ O2,
                                                           int S2, int ldq, int ldkv, int ldo, int Tq, float scale, int H,
-                                                          int n_qblocks) {
+                                                          int n_qblocks, int n_qsplit) {
   constexpr int QG = 2, MAXT = 5;                            // 1 text tile + up to 4 prompt tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [tile][K | V], 16 KiB per tile
   const int tid = threadIdx.x, lane = tid & 63;
@@ -324,7 +352,9 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
     const int nblocks = gridDim.x, q = nblocks >> 3, r = nblocks & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int qb = bid % n_qblocks, h = (bid / n_qblocks) % H, b = bid / (n_qblocks * H);
+  // a workgroup keeps the K / V image of its (utterance, head) and walks the query blocks qs, qs + n_qsplit, ..: at the
+  // throughput batch n_qsplit = 1 -- one workgroup per CU, one DMA flight per (utterance, head) instead of one per query block
+  const int qs = bid % n_qsplit, h = (bid / n_qsplit) % H, b = bid / (n_qsplit * H);
   const int nt2 = (S2 + BKV - 1) / BKV, n_tiles = 1 + nt2;
   // ---- every K / V piece of both problems: 16 pieces (1 KiB = 8 rows x 128 B) per tile, dealt over the 8 waves
   {
@@ -342,32 +372,45 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(smem + tile * 2 * TILE + which * TILE + j * 1024), 16, 0, 0);
     }
   }
-  const int q0 = (qb * 8 + wave) * (16 * QG);
   const int qi = lane & 15, g = lane >> 4;
   const float qscale = scale * 1.4426950408889634f;
   const uint32_t one2 = pack2<T>(1.0f, 1.0f);
   const uint4 ones = uint4{one2, one2, one2, one2};
   bool landed = false;
-  for (int prob = 0; prob < 2; ++prob) {
+  // the queries of a (query block, problem) phase are fetched one phase ahead: raw rows in registers while the previous phase
+  // computes, scaled and packed at the top of their own phase
+  uint4 qraw[QG][2];
+  auto fetch_q = [&](int qb, int prob) __attribute__((always_inline)) {
     const T* Q = prob == 0 ? Q1 : Q2;
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+      int qrow = (qb * 8 + wave) * (16 * QG) + qg * 16 + qi;
+      qrow = qrow < Tq ? qrow : Tq - 1;
+      const T* qp = Q + (static_cast<size_t>(b) * Tq + qrow) * ldq + h * HD;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) qraw[qg][ks] = *reinterpret_cast<const uint4*>(qp + ks * 32 + g * 8);
+    }
+  };
+  fetch_q(qs, 0);
+  for (int qb = qs; qb < n_qblocks; qb += n_qsplit) {
+  const int q0 = (qb * 8 + wave) * (16 * QG);
+  for (int prob = 0; prob < 2; ++prob) {
     T* O = prob == 0 ? O1 : O2;
     const int S = prob == 0 ? S1 : S2, t0 = prob == 0 ? 0 : 1, nt = prob == 0 ? 1 : nt2;
     uint4 qf[QG][2];
 #pragma unroll
-    for (int qg = 0; qg < QG; ++qg) {
-      int qrow = q0 + qg * 16 + qi;
-      qrow = qrow < Tq ? qrow : Tq - 1;
-      const T* qp = Q + (static_cast<size_t>(b) * Tq + qrow) * ldq + h * HD;
+    for (int qg = 0; qg < QG; ++qg)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         typedef T tvec8 __attribute__((ext_vector_type(8)));
-        const tvec8 e = __builtin_bit_cast(tvec8, *reinterpret_cast<const uint4*>(qp + ks * 32 + g * 8));
+        const tvec8 e = __builtin_bit_cast(tvec8, qraw[qg][ks]);
         qf[qg][ks] = uint4{pack2<T>(static_cast<float>(e[0]) * qscale, static_cast<float>(e[1]) * qscale),
                            pack2<T>(static_cast<float>(e[2]) * qscale, static_cast<float>(e[3]) * qscale),
                            pack2<T>(static_cast<float>(e[4]) * qscale, static_cast<float>(e[5]) * qscale),
                            pack2<T>(static_cast<float>(e[6]) * qscale, static_cast<float>(e[7]) * qscale)};
       }
-    }
+    if (prob == 0) fetch_q(qb, 1);
+    else if (qb + n_qsplit < n_qblocks) fetch_q(qb + n_qsplit, 0);
     if (!landed) {                                           // one wait for the whole workgroup's K / V image
       __syncthreads();                                       // (drains this wave's DMA pieces, then the barrier)
       landed = true;
@@ -474,6 +517,7 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
       }
     }
   }
+  }   // query blocks
   (void)MAXT;
 }
 
@@ -505,10 +549,13 @@ void set_attn_cross_resident(int v) { g_attn_cross_resident = v; }
 
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
   const long long cross_wgs = static_cast<long long>((a.Tq + 255) / 256) * a.H * a.B;
-  if ((g_attn_cross_resident == 2 || (g_attn_cross_resident == 1 && cross_wgs >= 256)) && a.Q2 != nullptr && a.key_len == nullptr &&
+  if ((g_attn_cross_resident >= 2 || (g_attn_cross_resident == 1 && cross_wgs >= 256)) && a.Q2 != nullptr && a.key_len == nullptr &&
       a.S <= BKV && a.S2 <= 4 * BKV) {
     const int n_qblocks = (a.Tq + 255) / 256;
-    const dim3 grid(static_cast<unsigned>(n_qblocks * a.H * a.B)), block(512);
+    int n_qsplit = (256 + a.H * a.B - 1) / (a.H * a.B);            // workgroups per (utterance, head): enough to cover the CUs
+    n_qsplit = n_qsplit < 1 ? 1 : n_qsplit > n_qblocks ? n_qblocks : n_qsplit;
+    if (g_attn_cross_resident == 3) n_qsplit = n_qblocks;              // tuning: one query block per workgroup (the first form)
+    const dim3 grid(static_cast<unsigned>(n_qsplit * a.H * a.B)), block(512);
     const size_t lds = static_cast<size_t>(1 + (a.S2 + BKV - 1) / BKV) * 2 * TILE;
 #define D3PM_CROSS(T)                                                                                                        \
     do {                                                                                                                     \
@@ -520,7 +567,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
       }                                                                                                                      \
       attn_cross_hd64<T><<<grid, block, lds, s>>>(static_cast<const T*>(a.Q), static_cast<const T*>(a.K),                     \
           static_cast<const T*>(a.V), static_cast<T*>(a.O), a.S, static_cast<const T*>(a.Q2), static_cast<const T*>(a.K2),    \
-          static_cast<const T*>(a.V2), static_cast<T*>(a.O2), a.S2, a.ldq, a.ldkv, a.ldo, a.Tq, a.scale, a.H, n_qblocks);    \
+          static_cast<const T*>(a.V2), static_cast<T*>(a.O2), a.S2, a.ldq, a.ldkv, a.ldo, a.Tq, a.scale, a.H, n_qblocks, n_qsplit); \
     } while (0)
     if (dtype == D3PM_F16) D3PM_CROSS(f16); else D3PM_CROSS(bf16);
 #undef D3PM_CROSS

@@ -15,7 +15,7 @@ import torch
 F32, F16, BF16 = 0, 1, 2
 ABI_VERSION = 2
 FLAG_GREEDY, FLAG_FORCE_GENERIC, FLAG_SEED_IN_HBM = 1, 2, 4
-K_GEMM, K_ATTN, K_SAMPLE, K_LN, K_ALL = 0, 1, 2, 3, 4
+K_GEMM, K_ATTN, K_SAMPLE, K_LN, K_GEMM_LN, K_ALL = 0, 1, 2, 3, 4, 5
 
 _DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 LIB_PATH = os.environ.get("D3PM_HIP_LIB") or os.path.normpath(
