@@ -359,6 +359,8 @@ int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, c
  *                         kernel and the logits never reach HBM (16-bit model, d_model a multiple of 32, MFMA family);
  *                         0 (default: measured faster) = the two-launch form (final GEMM, then d3pm_posterior_sample's
  *                         kernel).  Same ids either way.
+ * D3PM_TUNE_WORKSPACE_ALIAS: 1 (default) = the packed qkv rows and the MLP hidden rows of a block share one workspace region (they
+ *                         are never live together); 0 = separate regions.  Set before d3pm_workspace_bytes is called.
  * D3PM_TUNE_LAT_TILE:     tile of the latency GEMM (GEMM_VARIANT 4 / auto at M <= 1536): 0 = auto (fewest rounds over the 256 CUs,
  *                         then most workgroups), 1 / 2 / 3 = always 64 x 64 / 96 x 64 / 32 x 64.  Same results.
  * D3PM_TUNE_LN_PROLOGUE:  1 = wherever the latency GEMM (64 x 64 tiles, M <= 1536 rows) runs a LayerNorm-fed projection
@@ -375,7 +377,7 @@ int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, c
 enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2,
        D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4, D3PM_TUNE_FUSED_FINAL_SAMPLE = 5,
        D3PM_TUNE_ATTN_CROSS_RESIDENT = 6, D3PM_TUNE_GELU_TABLE = 7, D3PM_TUNE_ROW_PANEL = 8, D3PM_TUNE_LN_PROLOGUE = 9,
-       D3PM_TUNE_LAT_TILE = 10 };
+       D3PM_TUNE_LAT_TILE = 10, D3PM_TUNE_WORKSPACE_ALIAS = 11 };
 int d3pm_set_tuning(int knob, int value);
 
 /* Single-op entry of the fused final projection + posterior + draw (replaces `final` at ar_discrete.py:776 followed by

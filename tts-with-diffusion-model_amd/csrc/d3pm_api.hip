@@ -41,7 +41,7 @@ int final_sample(int dtype, const void* X, int ldx, const void* W, const void* b
 // logits image allows 2
 static int g_fused_final_sample = 0;
 // D3PM_TUNE_ROW_PANEL: projections onto the residual stream normalise their rows in the epilogue (d3pm_mfma_gemm_big.hip)
-// measured on the bench workload (tools/ab_tune.sh, profiles/round2_c_ab_row_panel.txt): 1 | 2 gains 0.9 %; fc2 (4) loses -- its
+// measured on the bench workload (tools/ab_tune.sh, profiles/round2_c_ab_throughput.txt): 1 | 2 gains 0.9 %; fc2 (4) loses -- its
 // K = 2048 product runs 30 us slower on 96 x 512 tiles than on 192 x 256, more than the norm1 launch it saves
 static int g_row_panel = 3;
 int read_big_gemm_stamp(unsigned long long* out);
@@ -128,6 +128,7 @@ static int run_layernorm(int dtype, const LayerNormArgs& a, uint32_t flags, hipS
 }
 
 // ---- workspace carve-up ----------------------------------------------------------------------
+static int g_ws_alias = 1;
 struct Workspace {
   char *x, *h, *h2, *qkv, *att, *att2, *mlp, *logits;
   size_t total;
@@ -142,12 +143,25 @@ static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
   w.x = take(n * d * es);
   w.h = take(n * d * es);
-  w.h2 = take(n * d * es);
-  w.qkv = take(n * 3 * d * es);
-  w.att = take(n * d * es);
-  w.att2 = take(n * d * es);
-  w.mlp = take(n * 4 * d * es);
-  w.logits = take(n * logits_ld(sh) * es);
+  w.h2 = take(n * d * es);           // adjacent to h: norm2 | norm22 outputs feed ONE [2n, d] query projection
+  // Regions that are never live together share memory (D3PM_TUNE_WORKSPACE_ALIAS): 350 -> 200 MB per 32 utterances beside a
+  // 256-MB Infinity Cache, +1.6 % tokens/s measured for the first pair alone (profiles/round2_c_ab_throughput.txt):
+  //   packed qkv rows -> cross-attention queries -> MLP hidden rows -> logits of the iteration;
+  //   norm22 output (dead once the query projection ran) -> prompt cross-attention output
+  if (g_ws_alias) {
+    const size_t big = n * 4 * d * es, lg = n * logits_ld(sh) * es;
+    w.mlp = take(big > lg ? big : lg);
+    w.qkv = w.mlp;
+    w.logits = w.mlp;
+    w.att = take(n * d * es);
+    w.att2 = w.h2;
+  } else {
+    w.qkv = take(n * 3 * d * es);
+    w.att = take(n * d * es);
+    w.att2 = take(n * d * es);
+    w.mlp = take(n * 4 * d * es);
+    w.logits = take(n * logits_ld(sh) * es);
+  }
   w.total = off;
   return w;
 }
@@ -835,10 +849,11 @@ int d3pm_set_tuning(int knob, int value) {
   if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || (value >= 2 && value <= 8))) { set_gemm_variant(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && ((value >= 0 && value <= 2) || (value >= 100 && value < 164))) { set_attn_qg(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && value >= 0 && value <= 2) { set_attn_pair_sequential(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 9 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465)) { set_big_gemm_mode(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 9 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465 || value == 513)) { set_big_gemm_mode(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GELU_TABLE && (value == 0 || value == 1)) { set_gelu_table(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_CROSS_RESIDENT && value >= 0 && value <= 3) { set_attn_cross_resident(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_FUSED_FINAL_SAMPLE && (value == 0 || value == 1)) { g_fused_final_sample = value; return D3PM_OK; }
+  if (knob == D3PM_TUNE_WORKSPACE_ALIAS && (value == 0 || value == 1)) { g_ws_alias = value; return D3PM_OK; }
   if (knob == D3PM_TUNE_LAT_TILE && value >= 0 && value <= 3) { set_lat_tile(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_LN_PROLOGUE && (value == 0 || value == 1)) { g_ln_prologue = value; return D3PM_OK; }
   if (knob == D3PM_TUNE_ROW_PANEL && value >= 0 && value <= 7) { g_row_panel = value; return D3PM_OK; }

@@ -428,8 +428,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
       pend_y = Y + static_cast<size_t>(m0 + wm * 96 + (lane & 15)) * ldy + n0 + wn * 64 + epilogue_nq(lane);
       pending = true;
     } else {
-      epilogue_store<T, EPI, 4, 6, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
-                                         n0 + wn * 64, lane, nullptr, gelu_tab);
+      epilogue_store<T, EPI, 4, 6, true, false, (MODE & 512) != 0>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
+                                                                   n0 + wn * 64, lane, nullptr, gelu_tab);
     }
     if (!more) break;
     t = t_next;
@@ -548,6 +548,11 @@ static int big_launch_geometry(int id, const LinearArgs& a, int n_tiles, int til
       case 465: return big_launch<U, 0, 2, 4, 465>(a, n_tiles, tiles_total, grid, lds, s);
       default: break;
     }
+  }
+  if (md == 513) {      // hand-placed schedule with non-temporal output stores (A/B: tests/ab_gemm.py)
+    if (id == 1) return big_launch<U, E, 1, 8, 513>(a, n_tiles, tiles_total, grid, lds, s);
+    if (id == 2) return big_launch<U, E, 2, 4, 513>(a, n_tiles, tiles_total, grid, lds, s);
+    return big_launch<U, E, 2, 2, 513>(a, n_tiles, tiles_total, grid, lds, s);
   }
   const bool hand = (md & 1) != 0;
   // deferred stores need a next tile to hide in (more tiles than persistent workgroups) and K >= 8 k-steps

@@ -105,7 +105,7 @@ __device__ __forceinline__ void swap_rows16(float& a, float& b) {
 // the caller stores group (mt, np) later at Y + (mw0 + (lane & 15) + 16 mt) * ldy + nw0 + epilogue_nq(lane) + 32 np.
 __device__ __forceinline__ int epilogue_nq(int lane) { const int g = lane >> 4; return (g & 1) * 16 + (g >> 1) * 8; }
 
-template <typename T, int EPI, int NT = 4, int MT = 4, bool kInteriorOnly = false, bool kPack = false>
+template <typename T, int EPI, int NT = 4, int MT = 4, bool kInteriorOnly = false, bool kPack = false, bool kNts = false>
 __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* __restrict__ bias, T* Y, int ldy,
                                                const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                int mask_period, int M, int N, int mw0, int nw0, int lane,
@@ -196,6 +196,7 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
         }
         const uintx4 grp = uintx4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
         if constexpr (kPack) packed[mt * NP + np] = grp;
+        else if constexpr (kNts) __builtin_nontemporal_store(grp, reinterpret_cast<uintx4*>(y + np * 32));   // streaming output: do not keep it in L2
         else *reinterpret_cast<uintx4*>(y + np * 32) = grp;
       }
       y += static_cast<size_t>(16) * ldy;
