@@ -66,7 +66,7 @@ def test_workspace_query_needs_no_gpu(built_lib):
     from vall_e.vall_e import _hip, synth
     sh = _hip.make_shape(synth.D3PMConfig.libritts(), torch.bfloat16)
     n = built_lib.d3pm_workspace_bytes(ctypes.byref(sh), 32)
-    assert 300e6 < n < 500e6
+    assert 150e6 < n < 260e6          # x, h, h2 | att2, att (25 MB each) + the shared qkv / mlp / logits region (100 MB)
     bad = _hip.make_shape(synth.D3PMConfig(d_model=30, n_heads=16), torch.float16)
     assert built_lib.d3pm_workspace_bytes(ctypes.byref(bad), 1) == 0
 
