@@ -168,7 +168,8 @@ def fp8_fast_path(dev, dtype, batch, cfg, sd32, texts, proms):
         dt = (time.perf_counter() - t0) / 2
         out[name] = {"seconds_per_batch": dt, "codec_tokens_per_s": batch * cfg.n_frames / dt}
     live = slice(0, cfg.n_frames)
-    out["id_agreement_fp8_vs_bf16"] = float((ids["bf16_50_steps"][:, live] == ids["fp8_50_steps"][:, live]).float().mean())
+    a, b = (ids[k].reshape(batch, -1)[:, live] for k in ("bf16_50_steps", "fp8_50_steps"))     # one utterance comes back 1-D
+    out["id_agreement_fp8_vs_bf16"] = float((a == b).float().mean())
     out["note"] = ("49 iterations (timesteps = 50), same synthetic weights except time_emb (random init for the shorter "
                    "schedule); fp8 = e4m3 rows / channels with fp32 scales for norm1->QKV, norm2|22->cross q, norm3->fc1")
     return out

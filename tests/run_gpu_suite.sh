@@ -21,7 +21,7 @@ for st in $STAGES; do
                echo "pmc $c rc=$rc"
              done; cd $GRAFT_REPO_ROOT; find gpurun_out/pmc_* -name "*.csv" | head;;
     prof1)   cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof1 -- python3 $GRAFT_REPO_ROOT/bench.py --batch 1 --steps 5 --warmup 1 --cpu-steps 0 --no-latency > $GRAFT_REPO_ROOT/gpurun_out/prof1.log 2>&1; rc=$?; cd $GRAFT_REPO_ROOT; tail -2 gpurun_out/prof1.log;;
-    prof)    cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-steps 0 --no-latency --no-nar --no-fp8 > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; rc=$?; cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/prof.log; find gpurun_out/prof -name "*stats*" | head;;
+    prof)    cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-steps 0 --no-latency --no-nar > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; rc=$?; cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/prof.log; find gpurun_out/prof -name "*stats*" | head;;
   esac
   echo "stage $st rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then ok=0; fi
