@@ -31,7 +31,10 @@ extern "C" {
 
 /* 2: + d3pm_ce_loss_rows, the fp8 entry points (d3pm_*_fp8), D3PM_FLAG_SEED_IN_HBM, tuning knobs 2..3, GEMM variant 5
  *    (additions only) */
-#define D3PM_ABI_VERSION 2
+/* 3: + d3pm_op_final_sample, d3pm_op_cond_embed, the fp32 training ops (d3pm_op_*_f32), d3pm_op_linear_rowpanel / _lnpro,
+ *    d3pm_prof_read_class, d3pm_debug_gemm_clock, tuning knobs 4..11, GEMM variants 6..8; the kernel class D3PM_K_GEMM_LN took
+ *    the value 4, so "every class" (D3PM_K_COUNT) is now 5 */
+#define D3PM_ABI_VERSION 3
 
 enum { D3PM_F32 = 0, D3PM_F16 = 1, D3PM_BF16 = 2 };
 

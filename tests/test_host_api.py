@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in declared:
         assert hasattr(built_lib, name), name
     from vall_e.vall_e import _hip as _h
-    assert built_lib.d3pm_abi_version() == _h.ABI_VERSION == 2
+    assert built_lib.d3pm_abi_version() == _h.ABI_VERSION == 3
 
 
 @pytest.mark.parametrize("timesteps", [100, 200])

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 F32, F16, BF16 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_GREEDY, FLAG_FORCE_GENERIC, FLAG_SEED_IN_HBM = 1, 2, 4
 K_GEMM, K_ATTN, K_SAMPLE, K_LN, K_GEMM_LN, K_ALL = 0, 1, 2, 3, 4, 5
 
