@@ -32,7 +32,7 @@ def timeit(fn, reps=30):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-ARMS = [(2, "shipped (QG 2)"), (1, "QG 1"), (101, "no v_exp"), (102, "no max / rescale"), (103, "no exp, no max"), (104, "no staging"),
+ARMS = [(2, "shipped (QG 2)"), (3, "QG 3 (48 queries per wave)"), (201, "shipped, two workgroups per CU"), (202, "shipped, one workgroup per CU"), (1, "QG 1"), (101, "no v_exp"), (102, "no max / rescale"), (103, "no exp, no max"), (104, "no staging"),
         (112, "no staging, no barriers"), (116, "no P.V"), (132, "no Q.K"), (148, "no MFMA products"), (115, "only the MFMA products"),
         (160, "only softmax VALU")]
 arms = [int(a) for a in sys.argv[1:]] or [a for a, _ in ARMS]

@@ -575,7 +575,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     return D3PM_OK;
   }
   const long long wgs2 = static_cast<long long>((a.Tq + 127) / 128) * a.H * a.B * (a.Q2 ? 2 : 1);
-  const int qg = g_attn_qg == 0 ? (wgs2 >= 4 * 256 ? 2 : 1) : g_attn_qg >= 100 ? 2 : g_attn_qg, per_block = 64 * qg;
+  const int qg = g_attn_qg == 0 ? (wgs2 >= 4 * 256 ? 2 : 1) : g_attn_qg >= 100 ? 2 : (g_attn_qg == 3 && (dtype != D3PM_BF16 || a.Q2)) ? 2 : g_attn_qg, per_block = 64 * qg;
   const int n_qblocks = (a.Tq + per_block - 1) / per_block;
   const int n_blocks1 = n_qblocks * a.H * a.B;
   const bool seq = a.Q2 != nullptr && (g_attn_pair_seq == 2 || (g_attn_pair_seq == 1 && n_blocks1 >= 512));
@@ -592,7 +592,20 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     if (seq) { if (qg == 1) D3PM_ATTN(T, 1, true); else D3PM_ATTN(T, 2, true); }           \
     else { if (qg == 1) D3PM_ATTN(T, 1, false); else D3PM_ATTN(T, 2, false); }             \
   } while (0)
-  if (g_attn_qg >= 100 && dtype == D3PM_BF16 && !a.Q2) {      // timing-only ablations of the QG = 2 kernel
+  if (g_attn_qg == 3 && dtype == D3PM_BF16 && !a.Q2) {        // three query groups per wave (A/B: fewer LDS reads per MFMA, two waves per SIMD)
+    D3PM_ATTN(bf16, 3, false);
+  } else if (g_attn_qg >= 200 && dtype == D3PM_BF16 && !a.Q2) {      // occupancy probe: the shipped QG = 2 kernel with idle dynamic LDS
+    const size_t pad = g_attn_qg == 201 ? 32 * 1024 : 96 * 1024;   // 201: two workgroups per CU, 202: one (three without)
+    static bool attr_set = false;
+    if (!attr_set) {
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_hd64<bf16, 2, false, 0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr_set = true;
+    }
+    attn_mfma_hd64<bf16, 2, false, 0><<<grid, block, pad, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K),
+        static_cast<const bf16*>(a.V), a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks, nullptr, nullptr, nullptr,
+        nullptr, 0, n_first, a.key_len);
+  } else if (g_attn_qg >= 100 && dtype == D3PM_BF16 && !a.Q2) {      // timing-only ablations of the QG = 2 kernel
 #define D3PM_ABL(A) case A: attn_mfma_hd64<bf16, 2, false, A><<<grid, block, 0, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), \
       static_cast<const bf16*>(a.V), a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks, nullptr, nullptr, nullptr, nullptr, 0, n_first, a.key_len); break
     switch (g_attn_qg - 100) {
