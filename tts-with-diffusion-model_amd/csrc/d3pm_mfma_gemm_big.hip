@@ -72,7 +72,7 @@ __device__ unsigned long long g_big_stamp[4];   // MODE bit 8: {shader clocks, 1
 template <typename T> struct RowPanelArgs {
   const T* X2; const T* lnw; const T* lnb; const T* lnw2; const T* lnb2; const T* film; T* lny; T* lny2; float eps;
 };
-constexpr int FUSE_DUAL = 1, FUSE_LN = 2, FUSE_LN2 = 4, FUSE_FILM = 8;
+constexpr int FUSE_DUAL = 1, FUSE_LN = 2, FUSE_LN2 = 4, FUSE_FILM = 8, FUSE_ABL_NOLN = 16;   // 16: timing-only (LayerNorm arithmetic skipped)
 
 template <typename T, int EPI, int WM, int WN, int MODE, int FUSE = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __restrict__ X, int ldx, const T* __restrict__ W,
@@ -333,7 +333,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
       T* yrow = Y + static_cast<size_t>(m0 + (lane & 15)) * ldy + n0 + wn * 64 + nq;
 #pragma unroll
       for (int j = 0; j < 12; ++j) *reinterpret_cast<uintx4*>(yrow + static_cast<size_t>((j / 2) * 16) * ldy + (j % 2) * 32) = xp[j];
-      if constexpr (kLn) {
+      if constexpr (kLn && (FUSE & FUSE_ABL_NOLN) != 0) {      // timing-only: the stores of the LayerNorm outputs without their arithmetic
+#pragma unroll
+        for (int np = 0; np < 2; ++np)
+#pragma unroll
+          for (int mt = 0; mt < 6; ++mt) {
+            const size_t off = static_cast<size_t>(m0 + mt * 16 + (lane & 15)) * 512 + n0 + wn * 64 + np * 32 + nq;
+            *reinterpret_cast<uintx4*>(rp.lny + off) = xp[mt * 2 + np];
+            if constexpr (kLn2) *reinterpret_cast<uintx4*>(rp.lny2 + off) = xp[mt * 2 + np];
+          }
+      } else if constexpr (kLn) {
         float* red = reinterpret_cast<float*>(smem + 2 * STAGE);              // [2][96 rows][8 waves] partial sums
         auto unpack = [&](int j, float (&v)[8]) __attribute__((always_inline)) {
           const Pack8<T> p = __builtin_bit_cast(Pack8<T>, xp[j]);
@@ -634,7 +643,8 @@ int row_panel_linear(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipS
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
     switch (kind) {
-      case 1: return row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2>(a, f, s);
+      case 1: return g_big_mode == 1025 ? row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2 | FUSE_ABL_NOLN>(a, f, s)
+                                        : row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2>(a, f, s);
       case 2: return row_panel_launch<U, EPI_R2, FUSE_DUAL | FUSE_LN | FUSE_FILM>(a, f, s);
       case 3: return row_panel_launch<U, EPI_R1 | EPI_MASK, FUSE_LN>(a, f, s);
       default: break;
