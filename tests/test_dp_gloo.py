@@ -1,6 +1,7 @@
 """The N>1 path on CPU: world_size-2 (and 3, uneven) gloo groups around the data-parallel sharding.
 The HIP generate call is replaced by a deterministic stand-in keyed by the *global* utterance index,
 so the test checks exactly what the DP layer owns: partitioning, utt0 offsets, gather order."""
+import datetime
 import os
 import socket
 
@@ -56,7 +57,7 @@ def _two_stage(dp, n_utts):
 
 def _worker(rank, world, port, n_utts, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from vall_e.vall_e import dp
     texts = [torch.tensor([i]) for i in range(n_utts)]
     out = dp.generate_audio_dp(_FakeModel(), texts, texts, seed=3, generate_fn=_fake_generate)
@@ -73,7 +74,7 @@ def test_dp_gather_equals_single_process(world, n_utts):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_utts, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_utts, q), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
@@ -104,7 +105,8 @@ def _grad_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from vall_e.vall_e.train import all_reduce_gradients
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
@@ -125,8 +127,8 @@ def test_gradient_all_reduce_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400) + 431
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
