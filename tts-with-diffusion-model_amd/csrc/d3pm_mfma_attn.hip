@@ -49,6 +49,10 @@ template <> __device__ __forceinline__ floatx4 mma<bf16>(uint4 a, uint4 b, float
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * ROWB + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
 
+template <class F> __device__ __forceinline__ void static_for4(F&& f) {
+  f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
+}
+
 constexpr float kDefer = 8.0f;   // log2 of the largest un-normalised probability tolerated before m_ref is raised
 
 // max over the four lanes l, l^16, l^32, l^48 on the VALU (no LDS round trip): after v_permlane16_swap of two copies
@@ -73,6 +77,25 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
 
 // ABL: timing-only ablation builds (WRONG results; tests/ab_attn.py): 1 no v_exp, 2 no maximum / rescale logic, 4 no K/V
 // staging after the first tile, 8 no barriers, 16 no P.V product, 32 no Q.K product
+// fragment reads whose completion is waited for by hand (ABL bit 6: every K and V fragment of a tile issued at the top of
+// the tile, counted lgkmcnt before each consumer) -- hipcc sinks a plain LDS load to the instruction before its first use
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_read_b128(u32x4& dst, uint32_t addr, int off) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+}
+__device__ __forceinline__ void lds_read_tr_b64(u32x2& dst, uint32_t addr, int off) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+}
+template <int N> __device__ __forceinline__ void lds_wait2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lds_wait_v(u32x2 (&v)[2][4][2]) {
+  asm volatile("s_waitcnt lgkmcnt(%16)"
+               : "+v"(v[0][0][0]), "+v"(v[0][0][1]), "+v"(v[0][1][0]), "+v"(v[0][1][1]), "+v"(v[0][2][0]), "+v"(v[0][2][1]), "+v"(v[0][3][0]),
+                 "+v"(v[0][3][1]), "+v"(v[1][0][0]), "+v"(v[1][0][1]), "+v"(v[1][1][0]), "+v"(v[1][1][1]), "+v"(v[1][2][0]), "+v"(v[1][2][1]),
+                 "+v"(v[1][3][0]), "+v"(v[1][3][1])
+               : "n"(N));
+}
+
 template <typename T, int QG, bool PAIR, int ABL = 0>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
 __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
                                                       const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo,
@@ -213,12 +236,39 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
         if constexpr (ABL & 32) {
 #pragma unroll
           for (int qg = 0; qg < QG; ++qg) s[qg][kt] = negm[qg] + floatx4{0.1f * kt, 0.2f, 0.3f * tile, 0.4f};
-        } else {
+        } else if constexpr ((ABL & 64) == 0) {
         uint4 kf = *reinterpret_cast<const uint4*>(kb + ok[ks] + kt * 16 * ROWB);
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) s[qg][kt] = mma<T>(kf, qf[qg][ks], ks == 0 ? negm[qg] : s[qg][kt]);
         }
       }
+    u32x2 vfr[2][4][2];
+    if constexpr ((ABL & 64) != 0) {
+      const uint32_t lbase = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem)) + BUF * 2 * TILE;
+      u32x4 kfr[4][2];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) lds_read_b128(kfr[kt][ks], lbase + ok[ks], kt * 16 * ROWB);
+      // the LDS counter holds 15 operations: the 16 V reads go out four at a time behind each key block's MFMAs, so that
+      // they return under the softmax; counts = reads younger than the fragments a step consumes
+      static_for4([&](auto KT) {
+        constexpr int kt = decltype(KT)::value;
+        constexpr int kWaitK[4] = {6, 8, 10, 11};
+        lds_wait2<kWaitK[kt]>(kfr[kt][0], kfr[kt][1]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int qg = 0; qg < QG; ++qg)
+            s[qg][kt] = mma<T>(__builtin_bit_cast(uint4, kfr[kt][ks]), qf[qg][ks], ks == 0 ? negm[qg] : s[qg][kt]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          constexpr int idx0 = kt * 4;
+          const int idx = idx0 + j, kb2 = idx >> 3, dt = (idx >> 1) & 3, half = idx & 1;   // constants after unrolling
+          lds_read_tr_b64(vfr[kb2][dt][half], lbase + TILE + ov[dt], (2 * kb2 + half) * 16 * ROWB);
+        }
+      });
+    }
     // lane holds scores (log2 domain, minus m_ref) of its query for keys tile*64 + kt*16 + 4g + r
     const bool ragged = (tile == n_tiles - 1) && (S & (BKV - 1));   // wave-uniform: only the last tile can be partial
     uint4 pf[QG][2];
@@ -283,16 +333,22 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
           acc_l[qg][0] += 1.0f;
         }
     } else {
+    if constexpr ((ABL & 64) != 0) lds_wait_v<0>(vfr);
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         // 16-lane group g, lane qi: address of row (key0 + qi>>2), columns 16dt + 4(qi&3) .. +3
-        typedef short4v __attribute__((address_space(3))) * lds_ptr;
-        short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + ov[dt] + (2 * kb2) * 16 * ROWB));
-        short4v vc = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + ov[dt] + (2 * kb2 + 1) * 16 * ROWB));
-        uint2 lo = __builtin_bit_cast(uint2, va), hi = __builtin_bit_cast(uint2, vc);
-        const uint4 vf = uint4{lo.x, lo.y, hi.x, hi.y};
+        uint4 vf;
+        if constexpr ((ABL & 64) != 0) {
+          vf = uint4{vfr[kb2][dt][0].x, vfr[kb2][dt][0].y, vfr[kb2][dt][1].x, vfr[kb2][dt][1].y};
+        } else {
+          typedef short4v __attribute__((address_space(3))) * lds_ptr;
+          short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + ov[dt] + (2 * kb2) * 16 * ROWB));
+          short4v vc = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb + ov[dt] + (2 * kb2 + 1) * 16 * ROWB));
+          uint2 lo = __builtin_bit_cast(uint2, va), hi = __builtin_bit_cast(uint2, vc);
+          vf = uint4{lo.x, lo.y, hi.x, hi.y};
+        }
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) acc_o[qg][dt] = mma<T>(vf, pf[qg][kb2], acc_o[qg][dt]);
       }
@@ -609,7 +665,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
 #define D3PM_ABL(A) case A: attn_mfma_hd64<bf16, 2, false, A><<<grid, block, 0, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), \
       static_cast<const bf16*>(a.V), a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks, nullptr, nullptr, nullptr, nullptr, 0, n_first, a.key_len); break
     switch (g_attn_qg - 100) {
-      D3PM_ABL(1); D3PM_ABL(2); D3PM_ABL(3); D3PM_ABL(4); D3PM_ABL(12); D3PM_ABL(16); D3PM_ABL(32); D3PM_ABL(48); D3PM_ABL(15); D3PM_ABL(60);
+      D3PM_ABL(64); D3PM_ABL(1); D3PM_ABL(2); D3PM_ABL(3); D3PM_ABL(4); D3PM_ABL(12); D3PM_ABL(16); D3PM_ABL(32); D3PM_ABL(48); D3PM_ABL(15); D3PM_ABL(60);
       default: D3PM_ATTN(bf16, 2, false);
     }
 #undef D3PM_ABL
