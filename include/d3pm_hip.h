@@ -346,7 +346,7 @@ int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, c
  *                         gives >= 4 workgroups per CU, else 1), 1 or 2; 3 = three groups (bf16 self-attention only; A/B arm:
  *                         fewer LDS reads per MFMA at two waves per SIMD, measured no faster).  Same results.  Values >= 100
  *                         select builds for tests/ab_attn.py (100 + bits 1..32: parts of the kernel removed, timing only, WRONG
- *                         results; 164: hand-placed fragment reads, same results; 201 / 202: the shipped kernel held to two /
+ *                         results; 164: hand-placed fragment reads, 228: K / V tiles by direct-to-LDS DMA, same results; 201 / 202: the shipped kernel held to two /
  *                         one workgroup per CU).
  * D3PM_TUNE_ATTN_PAIR_SEQUENTIAL: a paired attention launch (text + prompt cross-attention) on the tile-by-tile kernel: 2 = every
  *                         workgroup runs both problems, one after the other; 0 = the second half of the grid takes problem 2;

@@ -32,7 +32,7 @@ def timeit(fn, reps=30):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-ARMS = [(2, "shipped (QG 2)"), (164, "all fragment reads of a tile issued at its top (same results)"), (3, "QG 3 (48 queries per wave)"), (201, "shipped, two workgroups per CU"), (202, "shipped, one workgroup per CU"), (1, "QG 1"), (101, "no v_exp"), (102, "no max / rescale"), (103, "no exp, no max"), (104, "no staging"),
+ARMS = [(2, "shipped (QG 2)"), (228, "K/V tiles by direct-to-LDS DMA (same results)"), (164, "all fragment reads of a tile issued at its top (same results)"), (3, "QG 3 (48 queries per wave)"), (201, "shipped, two workgroups per CU"), (202, "shipped, one workgroup per CU"), (1, "QG 1"), (101, "no v_exp"), (102, "no max / rescale"), (103, "no exp, no max"), (104, "no staging"),
         (112, "no staging, no barriers"), (116, "no P.V"), (132, "no Q.K"), (148, "no MFMA products"), (115, "only the MFMA products"),
         (160, "only softmax VALU")]
 arms = [int(a) for a in sys.argv[1:]] or [a for a, _ in ARMS]
@@ -41,7 +41,7 @@ flops = 4.0 * B * H * T * T * 64
 ref = None
 for arm in arms:
     _hip.set_attn_query_groups(arm) if arm < 100 else _hip.check(_hip.lib().d3pm_set_tuning(1, arm), "tune")
-    if arm in (1, 2, 3, 164, 201, 202):                  # the arms that must give the shipped kernel's bits
+    if arm in (1, 2, 3, 164, 228, 201, 202):                  # the arms that must give the shipped kernel's bits
         o = _hip.op_attention(q, k, v, H, 0.125, family=_hip.FAMILY_MFMA)
         ref = o.clone() if ref is None else ref
         assert torch.equal(o, ref), f"arm {arm}: output differs from the first arm"

@@ -96,6 +96,16 @@ template <int N> __device__ __forceinline__ void lds_wait_v(u32x2 (&v)[2][4][2])
                : "n"(N));
 }
 
+// one 1-KiB direct-to-LDS piece (8 rows x 128 B: lane -> row lane >> 3, 16-byte chunk lane & 7) issued from asm: invisible to
+// hipcc's wait counters (a compiler-visible DMA is drained before the next ds_read), so the wait is placed by hand
+__device__ __forceinline__ void dma_piece(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
 template <typename T, int QG, bool PAIR, int ABL = 0>   // QG groups of 16 queries per wave (K/V fragments are read once per wave and reused)
 __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
                                                       const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo,
@@ -188,8 +198,31 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
   };
 
   const int n_tiles = (S + BKV - 1) / BKV;
-  Staged st = load_tile(0);
-  store_tile(smem, st);
+  // ABL bit 7 (same results): K / V tiles go global -> LDS directly, four 1-KiB pieces per wave and tile (pieces wave, wave + 4
+  // = K rows, wave + 8, wave + 12 = V rows), issued at the top of the previous tile; a lane fetches the 16-byte chunk that the
+  // swizzled image wants at its position
+  constexpr bool kDma = (ABL & 128) != 0;
+  const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int which = i >> 1, j = wave_u + 4 * (i & 1), row = 8 * j + (lane >> 3), cpos = lane & 7;
+      const int logical = which == 0 ? (cpos ^ ((row >> 1) & 7)) : (cpos ^ (((row >> 1) & 3) << 1));
+      int key = tile * BKV + row;
+      key = key < S ? key : S - 1;
+      const T* src = (which == 0 ? Kb : Vb) + static_cast<size_t>(key) * ldkv + logical * 8;
+      dma_piece(src, lds0 + buf * 2 * TILE + which * TILE + j * 1024);
+    }
+  };
+  Staged st;
+  if constexpr (kDma) {
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    st = load_tile(0);
+    store_tile(smem, st);
+  }
   __syncthreads();
 
   float m_ref[QG];
@@ -223,7 +256,11 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
     const char* kb = smem + BUF * 2 * TILE;
     const char* vb = kb + TILE;
     const bool more = tile + 1 < n_tiles;
-    if (more && !(ABL & 4)) st = load_tile(tile + 1);
+    if constexpr (kDma) {
+      if (more) dma_tile(tile + 1, BUF ^ 1);           // BUF ^ 1 was last read in the previous tile, behind its barrier
+    } else {
+      if (more && !(ABL & 4)) st = load_tile(tile + 1);
+    }
 
     // ---- S^T tile: 64 keys x (16 QG) queries per wave; each K fragment feeds QG MFMAs ----
     // The accumulator starts at -m_ref (one register quad per query group, shared by the four key tiles as the C
@@ -359,7 +396,11 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
 #pragma unroll
       for (int qg = 0; qg < QG; ++qg) acc_l[qg] = mma<T>(ones, pf[qg][kb2], acc_l[qg]);
     }
-    if (more && !(ABL & 4)) store_tile(smem + (BUF ^ 1) * 2 * TILE, st);
+    if constexpr (kDma) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile have landed
+    } else {
+      if (more && !(ABL & 4)) store_tile(smem + (BUF ^ 1) * 2 * TILE, st);
+    }
     if constexpr (!(ABL & 8)) __syncthreads();
   };
   for (int tile = 0; tile < n_tiles; tile += 2) {
@@ -665,7 +706,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
 #define D3PM_ABL(A) case A: attn_mfma_hd64<bf16, 2, false, A><<<grid, block, 0, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), \
       static_cast<const bf16*>(a.V), a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks, nullptr, nullptr, nullptr, nullptr, 0, n_first, a.key_len); break
     switch (g_attn_qg - 100) {
-      D3PM_ABL(64); D3PM_ABL(1); D3PM_ABL(2); D3PM_ABL(3); D3PM_ABL(4); D3PM_ABL(12); D3PM_ABL(16); D3PM_ABL(32); D3PM_ABL(48); D3PM_ABL(15); D3PM_ABL(60);
+      D3PM_ABL(64); D3PM_ABL(128); D3PM_ABL(1); D3PM_ABL(2); D3PM_ABL(3); D3PM_ABL(4); D3PM_ABL(12); D3PM_ABL(16); D3PM_ABL(32); D3PM_ABL(48); D3PM_ABL(15); D3PM_ABL(60);
       default: D3PM_ATTN(bf16, 2, false);
     }
 #undef D3PM_ABL
