@@ -138,3 +138,20 @@ def test_wrapper_rejects_tensors_the_c_side_would_overrun():
                      (torch.zeros(448, 2, dtype=torch.int32).t(), "layout"), ([1, 2], "type")):
         with pytest.raises(_hip.D3PMError):
             _hip._require(bad, "x_t", (2, 448), (torch.int32,), dev)
+
+
+def test_inputs_are_padded_truncated_and_validated_like_upstream():
+    """ar_discrete.py:711-735 zero-pads short and truncates over-long phoneme / prompt sequences to the model's fixed key
+    counts; an empty or mismatched batch is an error before anything touches the GPU."""
+    from vall_e.vall_e import AR
+    short, exact, long_ = torch.arange(1, 4), torch.arange(1, 51), torch.arange(1, 80)
+    assert AR._pad_rows(short, 50).tolist() == [1, 2, 3] + [0] * 47
+    assert torch.equal(AR._pad_rows(exact, 50), exact)
+    assert torch.equal(AR._pad_rows(long_, 50), long_[:50])
+    prom = torch.ones(7, 8, dtype=torch.long)
+    assert AR._pad_rows(prom, 398).shape == (398, 8) and AR._pad_rows(prom, 398)[7:].abs().sum() == 0
+    m = AR.reference_native()
+    with pytest.raises(ValueError):
+        m.generate_audio([], [])
+    with pytest.raises(ValueError):
+        m.generate_audio([short], [prom, prom])
