@@ -1,0 +1,21 @@
+"""Batch invariance across the dispatcher's regimes: utterance 0 must come out bit-identical whatever the batch it rides
+in -- latency GEMM and split cross-attention grid (1, 2), the 128 x 128 kernels (3 .. 8), resident cross-attention without row
+panels (11, 16, 24, 33), big tiles + row panels (32, 64)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_utterance_zero_is_the_same_in_every_batch_size(built_lib):
+    from vall_e.vall_e import AR, synth
+    cfg = synth.D3PMConfig.libritts()
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0))
+    m = m.to(torch.bfloat16).to("cuda:0")
+    texts, proms = synth.make_inputs(cfg, 64, 1)
+    ref = m.generate_audio(texts[:1], proms[:1], steps=5, seed=11).reshape(-1)
+    for b in (2, 3, 8, 11, 16, 24, 32, 33, 64):
+        out = m.generate_audio(texts[:b], proms[:b], steps=5, seed=11)
+        assert out.shape[0] == b
+        assert torch.equal(out[0], ref), f"batch {b}: utterance 0 differs in {(out[0] != ref).sum().item()} frames"
