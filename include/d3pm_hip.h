@@ -377,10 +377,12 @@ int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, c
  *                         d_model = 512, the dtype is 16-bit and batch * canvas is a multiple of 96: 1 = self-attention
  *                         out-projection + norm2 | norm22, 2 = both cross-attention out-projections + norm3 / FiLM, 4 = fc2 +
  *                         the next block's norm1.  Default 3 (fc2 measured slower fused).  Same results as the separate launches.
- * D3PM_TUNE_GEMM_BIG_MODE: schedule of the big-tile GEMM: 1 (default) / 0 = hand-placed / compiler-placed fragment reads (same
- *                         results);
- *                         >= 16 = timing-only ablation builds for tests/ab_gemm.py (WRONG results; bits: 16 no DMA, 32 no
- *                         MFMA, 64 no barriers, 128 no LDS reads, 256 clock stamp for d3pm_debug_gemm_clock). */
+ * D3PM_TUNE_GEMM_BIG_MODE: schedule of the big-tile GEMM: 1 (default) / 0 = hand-placed / compiler-placed fragment reads, 9 = the
+ *                         output stores of a tile issued inside the next tile's k-steps, 513 = non-temporal output stores,
+ *                         2049 = every DMA piece of a k-step issued at its top (all: same results, none faster);
+ *                         timing-only builds for tests/ab_gemm.py / ab_rowpanel.py (WRONG results; bits: 16 no DMA, 32 no
+ *                         MFMA, 64 no barriers, 128 no LDS reads, 256 clock stamp for d3pm_debug_gemm_clock, 4096 with 32 =
+ *                         the operand stream through registers; 1025 = row panels without their LayerNorm arithmetic). */
 enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2,
        D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4, D3PM_TUNE_FUSED_FINAL_SAMPLE = 5,
        D3PM_TUNE_ATTN_CROSS_RESIDENT = 6, D3PM_TUNE_GELU_TABLE = 7, D3PM_TUNE_ROW_PANEL = 8, D3PM_TUNE_LN_PROLOGUE = 9,

@@ -194,7 +194,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
         __builtin_amdgcn_s_barrier();      // every wave's pieces of this k-step have landed; stage S ^ 1 is no longer read
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ABL == 2) {
+      if constexpr (ABL == 2 && (MODE & 4096) != 0) {
+        // timing probe: the same pieces through registers (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA
+        uintx4 stg[NDMA];
+#pragma unroll
+        for (int p = 0; p < NDMA; ++p) {
+          if (p < XPW) {
+            int j = wave + NW * p;
+            if constexpr (XD % NW != 0) { if (j >= XD) j = (XD / NW) * NW + wave % (XD % NW); }
+            stg[p] = *reinterpret_cast<const uintx4*>(reinterpret_cast<const char*>(px + static_cast<size_t>(8 * j) * ldx) + ox);
+          } else {
+            const int j = wave + NW * (p - XPW);
+            stg[p] = *reinterpret_cast<const uintx4*>(reinterpret_cast<const char*>(pw + static_cast<size_t>(8 * j) * K) + ow);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < NDMA; ++p) {
+          int j = p < XPW ? wave + NW * p : wave + NW * (p - XPW);
+          if constexpr (XD % NW != 0) { if (p < XPW && j >= XD) j = (XD / NW) * NW + wave % (XD % NW); }
+          *reinterpret_cast<uintx4*>(smem + (S ^ 1) * STAGE + (p < XPW ? 0 : X_BYTES) + j * 1024 + lane * 16) = stg[p];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else if constexpr (ABL == 2) {
 #pragma unroll
         for (int g = 0; g < NDMA; ++g) dma(g, px, pw, nxt);
       } else if constexpr (kHand) {
@@ -221,7 +242,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
             if constexpr (g + 2 < 12) lds_read16(fx[(g + 2) % 3], (g + 2) / 6 ? ax1 : ax0, ((g + 2) % 6) * 16 * ROW_BYTES);
             if constexpr (ks == 0 && mt >= 2) lds_read16(fw1[mt - 2], aw1, (mt - 2) * 16 * ROW_BYTES);
           }
-          if constexpr (g < NDMA && ABL != 1) dma(g, px, pw, nxt);
+          if constexpr ((MODE & 2048) != 0) {                // A/B: every piece of the next k-step issued in front of the first MFMA group
+            if constexpr (g == 0 && ABL != 1) {
+#pragma unroll
+              for (int p = 0; p < NDMA; ++p) dma(p, px, pw, nxt);
+            }
+          } else if constexpr (g < NDMA && ABL != 1) dma(g, px, pw, nxt);
           constexpr int kWait[12] = {2, 2, 3, 4, 5, 5, 1, 2, 2, 2, 1, 0};
           if constexpr (kNoReads) {}
           else if constexpr (g == 0) lds_wait<kWait[g]>(fw0[0], fw0[1], fw0[2], fw0[3], fx[0]);
@@ -557,6 +583,11 @@ static int big_launch_geometry(int id, const LinearArgs& a, int n_tiles, int til
       case 465: return big_launch<U, 0, 2, 4, 465>(a, n_tiles, tiles_total, grid, lds, s);
       default: break;
     }
+  }
+  if (md == 4129 && E == 0 && id == 2) return big_launch<U, 0, 2, 4, 4129>(a, n_tiles, tiles_total, grid, lds, s);   // timing probe
+  if (md == 33 && E == 0 && id == 2) return big_launch<U, 0, 2, 4, 33>(a, n_tiles, tiles_total, grid, lds, s);       // its LDS-DMA twin
+  if (md == 2049 && E == 0) {      // A/B: all DMA pieces of a k-step issued at its top (tests/ab_gemm.py), plain epilogue only
+    if (id == 2) return big_launch<U, 0, 2, 4, 2049>(a, n_tiles, tiles_total, grid, lds, s);
   }
   if (md == 513) {      // hand-placed schedule with non-temporal output stores (A/B: tests/ab_gemm.py)
     if (id == 1) return big_launch<U, E, 1, 8, 513>(a, n_tiles, tiles_total, grid, lds, s);
