@@ -209,7 +209,20 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
   EmbedArgs e;
   e.tokens = x_t; e.frame_mask = frame_mask; e.canvas = T; e.table = w.resps_emb; e.Y = ws.x;
   e.M = n; e.d = d; e.n_classes = sh.n_classes;
-  D3PM_TRY(embed_tokens(dt, e, s));
+  // the first block's norm1 reads the embedding rows straight from the table and writes x beside its own output: one launch and
+  // one pass over x less per iteration (same bits: the gather is a copy)
+  bool embed_fused = false;
+  if (!use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && layers > 0) {
+    LayerNormArgs ln0;
+    ln0.X = w.resps_emb; ln0.Y = ws.h; ln0.w = w.blocks[0].norm1_w; ln0.b = w.blocks[0].norm1_b; ln0.M = n; ln0.d = d; ln0.eps = 1e-6f;
+    ln0.tokens = x_t; ln0.frame_mask = frame_mask; ln0.canvas = T; ln0.n_classes = sh.n_classes; ln0.Xout = ws.x;
+    if (fast_layernorm_supported(dt, ln0)) {
+      ProfScope p(D3PM_K_LN, s, 0.0, dtype_size(dt) * static_cast<double>(n) * d * 3.0);
+      D3PM_TRY(fast_layernorm(dt, ln0, s));
+      embed_fused = true;
+    }
+  }
+  if (!embed_fused) D3PM_TRY(embed_tokens(dt, e, s));
 
   // row-panel launches (D3PM_TUNE_ROW_PANEL): a projection that lands on the residual stream also writes the LayerNorm(s) the
   // block applies to the new rows next -- same bits, one launch and one pass over x less each
@@ -217,7 +230,7 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
   const long long rp_tiles = n / 96, rp_rounds = (rp_tiles + 255) / 256;
   const bool rp_fills = n % 96 == 0 && rp_tiles * 5 >= 256 * 4 && rp_tiles * 100 >= rp_rounds * 256 * 85;
   const int panel = (!use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && rp_fills && (dt == D3PM_F16 || dt == D3PM_BF16)) ? g_row_panel : 0;
-  bool norm1_done = false;      // the previous block's fc2 launch already wrote norm1(x) of this block to ws.h
+  bool norm1_done = embed_fused;   // norm1(x) of this block is already in ws.h (the embedding launch, or the previous block's fc2)
   // the opposite regime (one or two utterances, latency GEMM): LayerNorm runs as the prologue of the projection it feeds
   const bool lnpro = g_ln_prologue && !use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && (dt == D3PM_F16 || dt == D3PM_BF16);
 

@@ -15,17 +15,30 @@ template <typename T, int CH>   // CH = d / 512 chunks of 8 elements per lane
 __global__ __launch_bounds__(256) void layernorm_vec(const T* __restrict__ x, T* __restrict__ y,
                                                      const T* __restrict__ w, const T* __restrict__ b,
                                                      const T* __restrict__ w2, const T* __restrict__ b2,
-                                                     T* __restrict__ y2, const T* __restrict__ film, int M, float eps) {
+                                                     T* __restrict__ y2, const T* __restrict__ film, int M, float eps,
+                                                     const int32_t* __restrict__ tok, const uint8_t* __restrict__ frame_mask,
+                                                     int canvas, int n_classes, T* __restrict__ xout) {
   constexpr int d = CH * 512;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
   const T* xr = x + static_cast<size_t>(row) * d;
+  bool live = true;
+  if (tok) {                                  // x is the embedding table: this row = table[token] * frame mask (embed_rows_vec)
+    int id = tok[row];
+    id = id < 0 ? 0 : (id >= n_classes ? n_classes - 1 : id);
+    live = frame_mask[row % canvas] != 0;
+    xr = x + static_cast<size_t>(id) * d;
+  }
   float v[CH][8];
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     Vec8<T> raw = *reinterpret_cast<const Vec8<T>*>(xr + (c * 64 + lane) * 8);
+    if (tok) {
+      if (!live) raw = Vec8<T>{};
+      *reinterpret_cast<Vec8<T>*>(xout + static_cast<size_t>(row) * d + (c * 64 + lane) * 8) = raw;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { v[c][i] = static_cast<float>(raw.v[i]); s += v[c][i]; }
   }
@@ -70,7 +83,8 @@ template <typename T> int launch(const LayerNormArgs& a, hipStream_t s) {
   layernorm_vec<T, CH><<<grid, block, 0, s>>>(static_cast<const T*>(a.X), static_cast<T*>(a.Y),              \
                                               static_cast<const T*>(a.w), static_cast<const T*>(a.b),        \
                                               static_cast<const T*>(a.w2), static_cast<const T*>(a.b2),      \
-                                              static_cast<T*>(a.Y2), static_cast<const T*>(a.film), a.M, a.eps)
+                                              static_cast<T*>(a.Y2), static_cast<const T*>(a.film), a.M, a.eps,  \
+                                              a.tokens, a.frame_mask, a.canvas, a.n_classes, static_cast<T*>(a.Xout))
   switch (a.d / 512) {
     case 1: D3PM_LN(1); break;
     case 2: D3PM_LN(2); break;
@@ -88,6 +102,7 @@ bool fast_layernorm_supported(int dtype, const LayerNormArgs& a) {
   if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
   if (a.d != 512 && a.d != 1024 && a.d != 2048) return false;
   auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % 16) == 0; };
+  if (a.tokens && !(a.frame_mask && a.canvas > 0 && a.n_classes > 0 && a.Xout && al(a.Xout))) return false;
   return al(a.X) && al(a.Y) && al(a.w) && al(a.b) && al(a.w2) && al(a.b2) && al(a.Y2) && al(a.film);
 }
 

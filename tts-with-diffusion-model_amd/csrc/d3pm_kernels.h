@@ -50,6 +50,9 @@ struct LayerNormArgs {
   const void* w2 = nullptr; const void* b2 = nullptr; void* Y2 = nullptr;
   const void* film = nullptr;
   int M = 0, d = 0; float eps = 1e-6f;
+  // optional gather in front (the first block's norm1 directly on the token embedding, ar_discrete.py:753,127,131): row m of the
+  // input is table[tokens[m]] (zeros where frame_mask[m % canvas] == 0) with X = the table; the gathered rows also go to Xout
+  const int32_t* tokens = nullptr; const uint8_t* frame_mask = nullptr; int canvas = 0, n_classes = 0; void* Xout = nullptr;
 };
 
 // what the row-panel projection (d3pm_mfma_gemm_big.hip) does to the rows it has just finished: N = d_model = 512
