@@ -341,6 +341,8 @@ int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, c
  *                         5 = throughput schedule with one tile per workgroup (the non-persistent form of 2);
  *                         6 / 7 / 8 = as auto, but only the 192 x 256 / 96 x 512 / 192 x 128 (two 4-wave workgroups per CU) big
  *                             tile is considered, for any shape made of whole tiles.
+ *                         9 = the experimental five-slab ring schedule (d3pm_mfma_gemm_ring.hip; measured slower) where it
+ *                             applies, else as auto.
  *                         Results are bit-identical across schedules.
  * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention: 0 = auto (default: 2 when that still
  *                         gives >= 4 workgroups per CU, else 1), 1 or 2; 3 = three groups (bf16 self-attention only; A/B arm:

@@ -33,8 +33,8 @@ def gelu32(v):
     return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
 
 
-@pytest.fixture(params=[2, 3, 4, 5, 6, 7, 8], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency_r1", 4: "gemm_latency", 5: "gemm_one_tile",
-                                                          6: "gemm_big_192x256", 7: "gemm_big_96x512", 8: "gemm_big_192x128"}[v])
+@pytest.fixture(params=[2, 3, 4, 5, 6, 7, 8, 9], ids=lambda v: {2: "gemm_throughput", 3: "gemm_latency_r1", 4: "gemm_latency", 5: "gemm_one_tile",
+                                                             6: "gemm_big_192x256", 7: "gemm_big_96x512", 8: "gemm_big_192x128", 9: "gemm_ring"}[v])
 def gemm_variant(request, built_lib):
     """Both schedules of the MFMA GEMM must pass the same numerics (auto selection is restored afterwards)."""
     from vall_e.vall_e import _hip
@@ -132,7 +132,7 @@ def test_gemm_big_tiles_match_one_tile_kernel(built_lib, dtype, epi, M, N, K):
     r1 = torch.randn(M, N, generator=g).to(dtype).to(DEV) if epi.startswith("r1") else None
     r2 = torch.randn(M, N, generator=g).to(dtype).to(DEV) if epi == "r1r2" else None
     mask = (torch.rand(T, generator=g) < 0.8).to(torch.uint8).to(DEV) if epi == "r1mask" else None
-    outs, arms = [], [(5, 0), (6, 0), (6, 1), (7, 0), (7, 1), (8, 0), (8, 1)]
+    outs, arms = [], [(5, 0), (6, 0), (6, 1), (7, 0), (7, 1), (8, 0), (8, 1), (9, 1)]      # 9: the five-slab ring schedule
     try:
         for v, mode in arms:
             _hip.set_gemm_variant(v)

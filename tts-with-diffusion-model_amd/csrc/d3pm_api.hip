@@ -859,7 +859,7 @@ int d3pm_op_cond_embed(int dtype, int which, const int32_t* tokens, int n_levels
 }
 
 int d3pm_set_tuning(int knob, int value) {
-  if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || (value >= 2 && value <= 8))) { set_gemm_variant(value); return D3PM_OK; }
+  if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || (value >= 2 && value <= 9))) { set_gemm_variant(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && ((value >= 0 && value <= 3) || (value >= 100 && value <= 164) || value == 228 || value == 201 || value == 202)) { set_attn_qg(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && value >= 0 && value <= 2) { set_attn_pair_sequential(value); return D3PM_OK; }
   if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 9 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465 || value == 513 || value == 1025 || value == 2049 || value == 4129 || value == 33)) { set_big_gemm_mode(value); return D3PM_OK; }

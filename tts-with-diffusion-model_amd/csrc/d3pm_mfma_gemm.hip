@@ -384,6 +384,8 @@ bool panel64_ln_supported(int dtype, const LinearArgs& a, const LnPrologue& ln);
 int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s, const LnPrologue* ln = nullptr);
 int big_linear_tile(int dtype, const LinearArgs& a, int want);
 int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s);
+bool ring_linear_supported(int dtype, const LinearArgs& a);
+int ring_linear(int dtype, const LinearArgs& a, hipStream_t s);
 
 // The LayerNorm-prologue form exists for the latency schedule only: true where mfma_linear would pick that schedule anyway
 bool ln_prologue_linear_applies(int dtype, const LinearArgs& a, const LnPrologue& ln) {
@@ -397,7 +399,8 @@ int ln_prologue_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, hip
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   // All schedules accumulate in the same order, so the choice never changes a bit of the result.
   const bool ffn_act = a.act == ACT_RELU || a.act == ACT_SILU;
-  const bool autosel = g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 8);
+  if (g_gemm_variant == 9 && ring_linear_supported(dtype, a)) return ring_linear(dtype, a, s);   // experimental ring schedule
+  const bool autosel = g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 9);
   if (autosel) {
     const int id = big_linear_tile(dtype, a, g_gemm_variant == 6 ? 2 : g_gemm_variant == 7 ? 1 : g_gemm_variant == 8 ? 3 : 0);
     if (id) return big_linear(dtype, a, id, s);

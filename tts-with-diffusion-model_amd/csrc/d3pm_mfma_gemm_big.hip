@@ -532,6 +532,7 @@ int big_linear_tile(int dtype, const LinearArgs& a, int want) {
 
 static int g_big_mode = 1;      // kernel MODE template argument (tuning / ablation builds); 1 = shipped schedule (hand-placed reads)
 void set_big_gemm_mode(int v) { g_big_mode = v; }
+int big_gemm_mode() { return g_big_mode; }
 int read_big_gemm_stamp(unsigned long long* out) {
   D3PM_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_stamp), 2 * sizeof(unsigned long long)));
   return D3PM_OK;
@@ -564,6 +565,7 @@ static int big_launch_geometry(int id, const LinearArgs& a, int n_tiles, int til
   if (E == 0 && id == 3 && md >= 16) {
     switch (md) {
       case 17: return big_launch<U, 0, 2, 2, 17>(a, n_tiles, tiles_total, grid, lds, s);
+      case 33: return big_launch<U, 0, 2, 2, 33>(a, n_tiles, tiles_total, grid, lds, s);
       case 209: return big_launch<U, 0, 2, 2, 209>(a, n_tiles, tiles_total, grid, lds, s);
       default: break;
     }
