@@ -109,13 +109,15 @@ def _grad_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from vall_e.vall_e.train import all_reduce_gradients
     torch.manual_seed(0)
-    model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2), torch.nn.Linear(2, 2))
     for i, p in enumerate(model.parameters()):
         if rank == 1 and i == 4:
             continue                                      # a parameter that got no gradient on this rank: counts as zeros
+        if i >= 6:
+            continue                                      # no gradient on ANY rank (upstream's dead cross_attn2 / token_emb): stays None
         p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
     n = all_reduce_gradients(model, bucket_bytes=80)     # tiny buckets: several collectives, tensors never split
-    out = [p.grad.flatten().tolist() for p in model.parameters()]     # plain lists: no shared-memory handles through the queue
+    out = [None if p.grad is None else p.grad.flatten().tolist() for p in model.parameters()]     # plain lists: no shared-memory handles through the queue
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, n, out))
@@ -139,5 +141,8 @@ def test_gradient_all_reduce_world2():
     assert n0 == n1 and n0 > 1
     for i, (a, b) in enumerate(zip(g0, g1)):
         assert a == b
+        if i >= 6:
+            assert a is None, "a parameter without a gradient on every rank must keep .grad = None (as at world size 1)"
+            continue
         want = ((1 * (i + 1)) + (0 if i == 4 else 2 * (i + 1))) / 2.0
         assert all(abs(v - want) < 1e-6 for v in a), (i, a[0], want)

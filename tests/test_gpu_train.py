@@ -111,9 +111,10 @@ def test_rccl_world_size_1_gather_and_gradient_all_reduce():
     code = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path[:0] = [os.path.join(os.environ['ROOT'], 'tts-with-diffusion-model_amd')]
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', RANK='0', WORLD_SIZE='1')
+os.environ.update(MASTER_ADDR='127.0.0.1', RANK='0', WORLD_SIZE='1')          # MASTER_PORT: a free port picked by the parent
 torch.cuda.set_device(0)
-dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+import datetime
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0), timeout=datetime.timedelta(seconds=120))
 from vall_e.vall_e import dp
 from vall_e.vall_e.train import all_reduce_gradients
 ids = torch.arange(2 * 16, dtype=torch.int32, device='cuda').reshape(2, 16)
@@ -131,6 +132,11 @@ dist.barrier()
 dist.destroy_process_group()
 print('RCCL_OK', torch.cuda.nccl.version())
 """
-    env = dict(os.environ, ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as sock:                # a free rendezvous port (a fixed one can collide and hang the init)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

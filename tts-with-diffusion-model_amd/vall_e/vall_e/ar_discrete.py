@@ -335,7 +335,9 @@ class AR(SymmapState, nn.Module):
         """The training step's compute (reference: `engine.backward(engine(...))`, utils/engines.py:144-147 over
         ar_discrete.py:588-694): the loss of `forward` AND its gradient for every parameter the forward reads, accumulated
         into `param.grad` by the HIP backward kernels (vall_e/vall_e/train.py; fp32 model).  Follow it with
-        `train.all_reduce_gradients(self)` under torch.distributed and any torch.optim step.  Returns the loss."""
+        `train.all_reduce_gradients(self)` under torch.distributed and any torch.optim step.  Returns the loss.
+        Eval-mode arithmetic: the dropout the reference applies inside its condition encoders in train mode (p = 0.1 /
+        0.01, ar_discrete.py:216-230) is omitted (vall_e/vall_e/train.py)."""
         from .train import D3PMTrainer
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())

@@ -16,6 +16,12 @@ reads -- the DiT blocks (cross_attn2 and token_emb are dead upstream and stay gr
 via `timestep_fc` -- and, through the cached cross-attention K / V, into the two condition encoders (ar_discrete.py:216-230:
 two post-norm TransformerEncoder layers + a SiLU Mlp each) and their embeddings `text_emb` (padding row 0 excluded, as
 nn.Embedding(padding_idx=0) does) and `proms_emb`.
+
+Dropout is NOT applied: the step is the eval-mode forward (`model.eval()`), and the gradient fixtures were generated that
+way (tests/golden/make_golden.py gen_grads).  The reference trains with dropout active -- p = 0.1 inside both condition
+encoders' TransformerEncoderLayers and drop = 0.01 in their Mlp (ar_discrete.py:216-230) -- drawn from torch's global
+generator, a stream this build cannot reproduce; the DiT blocks themselves have dropout 0 (:109,123).  A training run
+that needs the regulariser has to add it outside this step.
 """
 from __future__ import annotations
 
@@ -309,7 +315,8 @@ class D3PMTrainer:
     @torch.no_grad()
     def forward_backward(self, text_list: Sequence[torch.Tensor], proms_list: Sequence[torch.Tensor], resps_list: Sequence[torch.Tensor],
                          *, seed: int = 0, timesteps: Optional[int] = None):
-        """The loss of AR.forward (mean over the utterances) and its gradient, accumulated into `param.grad`.
+        """The loss of AR.forward (mean over the utterances) and its gradient, accumulated into `param.grad`; eval-mode
+        arithmetic (no dropout in the condition encoders: module docstring).
         Returns (loss fp32 scalar tensor, [(dcond_text, dcond_prompt)] per utterance)."""
         m, cfg = self.model, self.model.cfg
         smp = m.sampler()
@@ -351,14 +358,22 @@ def all_reduce_gradients(model, *, bucket_bytes: int = 64 << 20, average: bool =
     """Data-parallel gradient reduction (the reference: DeepSpeed inside engine.backward / step, utils/engines.py:144-147):
     every parameter's .grad summed over the ranks of the default process group in buckets of <= `bucket_bytes` -- one flat
     buffer per bucket, one all-reduce each (backend "nccl" = RCCL over xGMI; ring all-reduce is per-link bound, so a few
-    large messages instead of one per tensor) -- then divided by the world size.  Parameters without a gradient on this
-    rank contribute zeros, so all ranks issue identical collectives."""
+    large messages instead of one per tensor) -- then divided by the world size.  A parameter that has a gradient on some
+    rank but not on this one contributes zeros, so all ranks issue identical collectives; a parameter without a gradient
+    on EVERY rank (upstream's dead `cross_attn2` / `token_emb` tensors) is left out and keeps `.grad = None`, exactly as at
+    world size 1 -- otherwise weight decay would touch it in data-parallel runs only (one small MAX all-reduce of the
+    has-gradient bitmask decides that)."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
     world = dist.get_world_size()
     params = [p for p in model.parameters() if p.requires_grad]
-    n_coll, i = 0, 0
+    if not params:
+        return 0
+    has = torch.tensor([1 if p.grad is not None else 0 for p in params], dtype=torch.int32, device=params[0].device)
+    dist.all_reduce(has, op=dist.ReduceOp.MAX)
+    params = [p for p, h in zip(params, has.tolist()) if h]
+    n_coll, i = 1, 0
     while i < len(params):
         bucket, size = [], 0
         while i < len(params) and (not bucket or size + params[i].numel() * 4 <= bucket_bytes):
