@@ -50,12 +50,13 @@ def _audit(got, want, values, rows):
 
 
 # ---- (a) NAR at the measured size --------------------------------------------------------------------------------
-@pytest.mark.parametrize("tag,dtype,tol_max,tol_mean,tie", [("f16", torch.float16, 6e-2, 6e-3, 0.5),
-                                                            ("bf16", torch.bfloat16, 4e-1, 4e-2, 3.0)])
+@pytest.mark.parametrize("tag,dtype,tol_max,tol_mean,tie", [("f16", torch.float16, 2.5e-2, 4e-3, 0.1),
+                                                            ("bf16", torch.bfloat16, 2e-1, 3e-2, 1.0)])
 def test_nar_registry_size_mfma_against_the_oracle(built_lib, tag, dtype, tol_max, tol_mean, tie):
     """d = 1024, 16 heads, 12 layers: logits are O(8) after twelve residual blocks, so one quantum of the storage type is
-    8e-3 (fp16) / 6e-2 (bf16) there; asserted max |err| 6e-2 / 4e-1 and mean |err| 6e-3 / 4e-2 (measured values land in
-    gpurun_out/parity_report.json).  Level 2 with levels 0..2 given exercises the level-summed response embedding and a
+    8e-3 (fp16) / 6e-2 (bf16) there; asserted max |err| 2.5e-2 / 2e-1 and mean |err| 4e-3 / 3e-2 (measured on MI355X: max
+    7.8e-3 / 6.3e-2 = ONE quantum, mean 1.3e-3 / 1.05e-2; sampled ids differ on 0.2 % / 2.2 % of the frames, each a race the
+    oracle decided by < 0.008 / 0.28; profiles/round3_a_parity_report_measured_paths.json).  Level 2 with levels 0..2 given exercises the level-summed response embedding and a
     non-trivial AdaLN row.  The draw divides the logits by T = 0.2, i.e. multiplies their noise by 5: `tie` is that noise."""
     from vall_e.vall_e import NAR, synth
     cfg = synth.NARConfig()
@@ -94,13 +95,13 @@ def test_nar_registry_size_mfma_against_the_oracle(built_lib, tag, dtype, tol_ma
     REPORT[f"nar_d1024_{tag}_sampled_id_mismatch_frac"] = mism / total
     REPORT[f"nar_d1024_{tag}_sampled_id_worst_gap"] = worst
     assert worst < tie, f"a sampled NAR id differs where the oracle's race was decided by {worst}"
-    assert mism / total < (0.02 if dtype == torch.float16 else 0.12)
+    assert mism / total < (0.01 if dtype == torch.float16 else 0.06)
 
 
 def test_nar_mfma_vs_generic_bound_is_the_bf16_quantum(built_lib):
-    """tests/test_gpu_nar.py bounds MFMA-vs-generic logits at d = 512 / 2 layers by 0.25 (bf16).  Here the same comparison
-    in fp16 (quantum 2^-10 relative instead of 2^-7): the bound drops by the ratio of the quanta, which shows the 0.25 is
-    rounding noise of the storage type (flash-style softmax, accumulation order), not a family-specific error."""
+    """MFMA-vs-generic logits at d = 512 / 2 layers in both storage types: the difference scales with the quantum of the type
+    (fp16 2^-10 vs bf16 2^-7 relative: measured 0.002 vs 0.017, ratio 8), i.e. it is rounding noise of the storage type
+    (flash-style softmax, accumulation order), not a family-specific error.  Asserted at ~4x the measured values."""
     from vall_e.vall_e import NAR, _hip, synth
     cfg = synth.NARConfig(d_model=512, n_heads=8, n_layers=2)
     out = {}
@@ -119,7 +120,7 @@ def test_nar_mfma_vs_generic_bound_is_the_bf16_quantum(built_lib):
             err = max(err, (lg[b, tt + tp + 2: tt + tp + 2 + tr].float() - lg_gen[b, tt + tp + 2: tt + tp + 2 + tr].float()).abs().max().item())
         out[tag] = err
     REPORT["nar_d512_mfma_vs_generic_logits_max_abs_err"] = out
-    assert out["f16"] < 0.04 and out["bf16"] < 0.25, out
+    assert out["f16"] < 0.01 and out["bf16"] < 0.08, out          # measured on MI355X: 0.002 / 0.017
 
 
 # ---- (b) VCTK long-prompt shape ------------------------------------------------------------------------------------

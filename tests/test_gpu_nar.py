@@ -71,7 +71,7 @@ def test_nar_mfma_family_and_batch_independence(built_lib):
         tt, tp, tr = (int(v) for v in lens[b])
         a = lg[b, tt + tp + 2: tt + tp + 2 + tr].float()
         c = lg_gen[b, tt + tp + 2: tt + tp + 2 + tr].float()
-        assert (a - c).abs().max().item() < 0.25
+        assert (a - c).abs().max().item() < 0.08          # measured 0.017 (one bf16 quantum at |logit| ~ 4); was 0.25
     batch = m(texts, proms, resps, seed=3)
     for b in range(3):
         one = m([texts[b]], [proms[b]], [resps[b]], seed=3, utt0=b)
