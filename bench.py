@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket GEMM launches with HIP events (roofline.achieved is then 0): measures what the "
                          "event pairs cost the timed region")
-    ap.add_argument("--tune", default="", help="A/B ONLY: comma-separated knob=value pairs for d3pm_set_tuning "
-                    "(include/d3pm_hip.h), e.g. 8=0; the JSON line records them and is not the headline configuration")
+    ap.add_argument("--tune", default="", help="A/B ONLY: comma-separated field=value pairs of d3pm_tuning "
+                    "(include/d3pm_hip.h), e.g. row_panel=0; the JSON line records them and is not the headline configuration")
     ap.add_argument("--cpu-only", action="store_true",
                     help="time only the CPU port (no GPU needed) and print its JSON: the container calibration under profiles/")
     ap.add_argument("--profile-iters", type=int, default=0,
@@ -293,8 +293,8 @@ def main():
     g.build()
     from vall_e.vall_e import AR, _hip, dp, synth
     for kv in filter(None, args.tune.split(",")):
-        knob, value = (int(v) for v in kv.split("="))
-        _hip.check(_hip.lib().d3pm_set_tuning(knob, value), "d3pm_set_tuning")
+        field, value = kv.split("=")
+        _hip.set_tuning_field(field.strip(), int(value))
 
     cfg = {"libritts": synth.D3PMConfig.libritts, "native": synth.D3PMConfig.native,
            "vctk": synth.D3PMConfig.vctk_long_prompt}[args.config]()

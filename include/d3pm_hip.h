@@ -6,6 +6,8 @@
  * (paths relative to /root/reference/vall_e/vall_e/).
  *
  * Conventions
+ *   - the library keeps NO mutable process-wide state (thread-compatible): schedule choices travel in `d3pm_tuning`
+ *     through the shape structs, timing hooks in a caller-owned `d3pm_prof`; the only thread-local is the error string;
  *   - every pointer marked "device" is HBM memory owned by the caller (e.g. a torch tensor's
  *     data_ptr()); nothing is allocated, freed or synchronised inside the library;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*), so calls are capturable
@@ -34,7 +36,12 @@ extern "C" {
 /* 3: + d3pm_op_final_sample, d3pm_op_cond_embed, the fp32 training ops (d3pm_op_*_f32), d3pm_op_linear_rowpanel / _lnpro,
  *    d3pm_prof_read_class, d3pm_debug_gemm_clock, tuning knobs 4..11, GEMM variants 6..8; the kernel class D3PM_K_GEMM_LN took
  *    the value 4, so "every class" (D3PM_K_COUNT) is now 5 */
-#define D3PM_ABI_VERSION 3
+/* 4: the tuning knobs moved from process-wide state (d3pm_set_tuning) into `d3pm_tuning`, reached through the shape structs
+ *    (and a trailing argument of d3pm_op_linear / d3pm_op_attention); the profiling hooks became a handle (d3pm_prof);
+ *    the library keeps no mutable global state besides the thread-local error string.  The experiment-only entry points
+ *    (d3pm_set_tuning's ablation arms, d3pm_op_final_sample, d3pm_op_linear_lnpro, d3pm_debug_gemm_clock) left the product:
+ *    they live in libd3pm_hip_ab.so, include/d3pm_hip_ab.h. */
+#define D3PM_ABI_VERSION 4
 
 enum { D3PM_F32 = 0, D3PM_F16 = 1, D3PM_BF16 = 2 };
 
@@ -55,6 +62,49 @@ enum {
                                   new seed (measured: no faster than eager launches, 66.6 vs 66.3 ms per utterance) */
 };
 
+/* Schedule choices.  Every value of every field gives bit-identical results: the fields select between shipped schedules
+ * only.  A NULL `tuning` pointer anywhere means d3pm_tuning_default().  The struct is read during the call and never
+ * retained; two threads may use different tunings at the same time.
+ *   gemm_variant       0 = auto (default): big-tile persistent schedule (192 x 256 or 96 x 512 tiles, eight waves, one workgroup
+ *                          per CU) when the shape divides into >= 200 such tiles that fill whole rounds of the 256 CUs, else the
+ *                          latency schedule (64 x 64 tiles, whole-K operand panels in flight) for M <= 1536 rows, the 128 x 128
+ *                          throughput schedule otherwise;
+ *                      2 = always the throughput schedule (one LDS stage, 4 workgroups per CU; persistent over the 128 x 128
+ *                          tiles when M and N are multiples of 128 and there are >= 512 tiles, else as 5);
+ *                      3 = always the round-1 latency schedule (128 x 128 tiles, two stages, asm DMA prefetch);
+ *                      4 = always the latency schedule (64 x 64 tiles, every DMA piece of K <= 512 in flight at once);
+ *                      5 = throughput schedule with one tile per workgroup (the non-persistent form of 2);
+ *                      6 / 7 / 8 = as auto, but only the 192 x 256 / 96 x 512 / 192 x 128 (two 4-wave workgroups per CU) big
+ *                          tile is considered, for any shape made of whole tiles.
+ *   gemm_persist_slots resident workgroups of the persistent 128 x 128 schedule, a multiple of 8 (default 1024 = 4 per CU).
+ *   lat_tile           tile of the latency GEMM: 0 = auto (fewest rounds over the 256 CUs, then most workgroups),
+ *                      1 / 2 / 3 = always 64 x 64 / 96 x 64 / 32 x 64.
+ *   attn_query_groups  16-query groups per wave of the MFMA attention: 0 = auto (2 when that still gives >= 4 workgroups
+ *                      per CU, else 1), 1 or 2.
+ *   attn_pair_sequential  a paired attention launch (text + prompt cross-attention) on the tile-by-tile kernel: 2 = every
+ *                      workgroup runs both problems one after the other; 0 = the second half of the grid takes problem 2;
+ *                      1 (default) = auto: sequential while that still leaves >= 2 workgroups per CU.
+ *   attn_cross_resident  the cross-attention pair of a block (<= 64 and <= 256 keys) with every K / V tile of both problems
+ *                      fetched into LDS once per (utterance, head) by a workgroup of eight waves that then walks that head's
+ *                      256-query blocks: 2 = always, 0 = never (tile-by-tile kernel), 1 (default) = auto: when there is at least
+ *                      one such workgroup per CU (batch >= 11 at 768 rows and 8 heads); 3 = as 2 with one query block per workgroup.
+ *   row_panel          bit mask of the block's projections that run as row-panel launches (d3pm_op_linear_rowpanel) when
+ *                      d_model = 512, the dtype is 16-bit and batch * canvas is a multiple of 96: 1 = self-attention
+ *                      out-projection + norm2 | norm22, 2 = both cross-attention out-projections + norm3 / FiLM, 4 = fc2 + the
+ *                      next block's norm1.  Default 3 (fc2 measured slower fused).
+ *   workspace_alias    1 (default) = the packed qkv rows, the MLP hidden rows and the logits of an iteration share one
+ *                      workspace region (never live together); 0 = separate regions.  d3pm_workspace_bytes and the step /
+ *                      loop calls must see the same value.
+ *   prof               optional timing hooks (d3pm_prof_create below), NULL = none. */
+struct d3pm_prof;
+typedef struct d3pm_tuning {
+  int32_t gemm_variant, gemm_persist_slots, lat_tile;
+  int32_t attn_query_groups, attn_pair_sequential, attn_cross_resident;
+  int32_t row_panel, workspace_alias;
+  struct d3pm_prof *prof;
+} d3pm_tuning;
+void d3pm_tuning_default(d3pm_tuning *t);
+
 typedef struct d3pm_shape {
   int32_t d_model;    /* 32 upstream (ar_discrete.py:208); 512 asked by get_model (__init__.py:26) */
   int32_t n_heads;    /* 16 upstream (ar_discrete.py:238)                                          */
@@ -66,6 +116,7 @@ typedef struct d3pm_shape {
   int32_t mask_id;    /* absorbing id 512 (:332)                                                   */
   int32_t timesteps;  /* 100 (:207); the loop runs t = timesteps-1 .. 1 (:750)                     */
   int32_t dtype;      /* D3PM_F32 / D3PM_F16 / D3PM_BF16                                           */
+  const d3pm_tuning *tuning;   /* schedule choices of the calls made with this shape, or NULL (defaults)   */
 } d3pm_shape;
 
 /* One DiT block's parameters (ar_discrete.py:103-124), device pointers, elements of `dtype`,
@@ -248,6 +299,7 @@ int d3pm_uniform(uint64_t seed, int t, uint32_t row0, int rows, int n_classes, i
  * temperature sampling of the response rows (Gumbel-max over Philox stream 2 instead of torch's multinomial). */
 typedef struct d3pm_nar_shape {
   int32_t d_model, n_heads, n_layers, n_tokens, n_prom_levels, n_resp_levels, dtype;
+  const d3pm_tuning *tuning;   /* as in d3pm_shape */
 } d3pm_nar_shape;
 
 typedef struct d3pm_nar_block_weights {
@@ -290,7 +342,7 @@ int d3pm_nar_level(const d3pm_nar_shape *shape, const d3pm_nar_weights *w, int b
  *   layernorm: Y = LN(X)*w + b over the last dim (eps 1e-6), optional FiLM vector [2d] */
 int d3pm_op_linear(int dtype, int family, const void *X, int ldx, const void *W, const void *bias, void *Y,
                    int ldy, const void *R1, const void *R2, int ldr, const uint8_t *row_mask,
-                   int mask_period, int M, int N, int K, int act, void *stream);
+                   int mask_period, int M, int N, int K, int act, const d3pm_tuning *tuning, void *stream);
 /* fp8 (OCP e4m3) fast path, BASELINE.json configs[4] (no reference counterpart: the reference is fp16 only):
  *   layernorm_fp8: Y8[M][512] = e4m3(LN(X)*w + b [FiLM] / sx[m]), sx[m] = absmax of the row / 448 (fp32), the 16-bit
  *                  LayerNorm result being exactly d3pm_op_layernorm's;
@@ -301,18 +353,10 @@ int d3pm_op_linear_fp8(int out_dtype, const void *X8, int ldx, const float *sx, 
 int d3pm_op_layernorm_fp8(int dtype, const void *X, void *Y8, float *sx, const void *w, const void *b,
                           const void *film, int M, int d, float eps, void *stream);
 int d3pm_op_attention(int dtype, int family, const void *Q, int ldq, const void *K, const void *V, int ldkv,
-                      void *O, int ldo, int B, int Tq, int S, int H, int hd, float scale, void *stream);
+                      void *O, int ldo, int B, int Tq, int S, int H, int hd, float scale, const d3pm_tuning *tuning,
+                      void *stream);
 int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const void *b, const void *film,
                       int M, int d, float eps, void *stream);
-/* LayerNorm-prologue projection (d_model = 512, latency regime): Y[M][N] = act(LN(X) W^T + bias) with X [.][512] the
- * UN-normalised residual stream -- the 64-row operand panels of the latency GEMM are whole rows, so each workgroup normalises
- * them in LDS before its MFMAs (ar_discrete.py:131-132 norm1 -> self-attention in-projection, :145-159 norm3 + FiLM -> fc1).
- * With ln2_w / ln2_b: M = 2 m rows, output rows >= m are source rows 0 .. m-1 under the second LayerNorm (:136-142, norm2 |
- * norm22 -> the text and prompt query projections through the shared cross_attn weights).  Bit-identical to
- * d3pm_op_layernorm followed by d3pm_op_linear.  W [N][512], Y [M][N], act 0 none / 1 GELU. */
-int d3pm_op_linear_lnpro(int dtype, const void *X, const void *W, const void *bias, void *Y, int M, int N, int act,
-                         const void *ln_w, const void *ln_b, const void *ln2_w, const void *ln2_b, const void *film,
-                         float eps, void *stream);
 /* Row-panel projection (d_model = 512): a Linear whose output is added to the residual stream, together with the LayerNorm(s)
  * the block applies to the new rows next, in ONE launch -- a workgroup owns whole rows (96 x 512 tiles), so the row moments
  * are reduced on chip.  Three forms, each bit-identical to the launches it replaces (d3pm_op_linear, then d3pm_op_layernorm):
@@ -329,91 +373,19 @@ int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, c
                             const void *ln_b, void *ln_y, const void *ln2_w, const void *ln2_b, void *ln2_y,
                             const void *film, float eps, void *stream);
 
-/* Tuning knobs (process-wide; defaults are what bench.py measures).
- * D3PM_TUNE_GEMM_VARIANT: 0 = auto (default): big-tile persistent schedule (192 x 256 or 96 x 512 tiles, eight waves,
- *                             one workgroup per CU) when the shape divides into >= 200 such tiles that fill whole rounds
- *                             of the 256 CUs, else latency schedule (64 x 64 tiles, whole-K operand panels in flight) for
- *                             M <= 1536 rows, 128 x 128 throughput schedule otherwise;
- *                         2 = always the throughput schedule (one LDS stage, 4 workgroups per CU; persistent over the
- *                             128 x 128 tiles when M and N are multiples of 128 and there are >= 512 tiles, else as 5);
- *                         3 = always the round-1 latency schedule (128 x 128 tiles, two stages, asm DMA prefetch);
- *                         4 = always the latency schedule (64 x 64 tiles, every DMA piece of K <= 512 in flight at once);
- *                         5 = throughput schedule with one tile per workgroup (the non-persistent form of 2);
- *                         6 / 7 / 8 = as auto, but only the 192 x 256 / 96 x 512 / 192 x 128 (two 4-wave workgroups per CU) big
- *                             tile is considered, for any shape made of whole tiles.
- *                         9 = the experimental five-slab ring schedule (d3pm_mfma_gemm_ring.hip; measured slower) where it
- *                             applies, else as auto.
- *                         Results are bit-identical across schedules.
- * D3PM_TUNE_ATTN_QUERY_GROUPS: 16-query groups per wave of the MFMA attention: 0 = auto (default: 2 when that still
- *                         gives >= 4 workgroups per CU, else 1), 1 or 2; 3 = three groups (bf16 self-attention only; A/B arm:
- *                         fewer LDS reads per MFMA at two waves per SIMD, measured no faster).  Same results.  Values >= 100
- *                         select builds for tests/ab_attn.py (100 + bits 1..32: parts of the kernel removed, timing only, WRONG
- *                         results; 164: hand-placed fragment reads, 228: K / V tiles by direct-to-LDS DMA, same results; 201 / 202: the shipped kernel held to two /
- *                         one workgroup per CU).
- * D3PM_TUNE_ATTN_PAIR_SEQUENTIAL: a paired attention launch (text + prompt cross-attention) on the tile-by-tile kernel: 2 = every
- *                         workgroup runs both problems, one after the other; 0 = the second half of the grid takes problem 2;
- *                         1 (default) = auto: sequential while that still leaves >= 2 workgroups per CU.
- * D3PM_TUNE_GEMM_PERSIST_SLOTS: resident workgroups of the persistent throughput schedule, a multiple of 8
- *                         (default 1024 = 4 per CU).
- * D3PM_TUNE_GELU_TABLE:   1 = the bf16 GELU epilogue of the 192 x 256 big-tile and the latency GEMM reads rn_bf16(gelu(v)) from
- *                         an 8.5 KiB LDS table filled on the device by the arithmetic path itself (bit-identical results);
- *                         0 (default: the table measured slower, 86 vs 73 us on fc1) = always the arithmetic path.
- * D3PM_TUNE_ATTN_CROSS_RESIDENT: the text + prompt cross-attention pair of a block (<= 64 and <= 256 keys) with every K / V tile of
- *                         both problems fetched into LDS once per (utterance, head) -- one wait, no per-tile barrier -- by a
- *                         workgroup of eight waves that then walks that head's 256-query blocks (the next block's queries
- *                         prefetched): 2 = always, 0 = never (tile-by-tile kernel), 1 (default) = auto: when there is at least one
- *                         such workgroup per CU (batch >= 11 at 768 rows and 8 heads); 3 = as 2 with one query block per
- *                         workgroup (the first form, kept for A/B).  Same results.
- * D3PM_TUNE_FUSED_FINAL_SAMPLE: 1 = inside d3pm_sample_loop the final projection, the posterior and the draw are one
- *                         kernel and the logits never reach HBM (16-bit model, d_model a multiple of 32, MFMA family);
- *                         0 (default: measured faster) = the two-launch form (final GEMM, then d3pm_posterior_sample's
- *                         kernel).  Same ids either way.
- * D3PM_TUNE_WORKSPACE_ALIAS: 1 (default) = the packed qkv rows and the MLP hidden rows of a block share one workspace region (they
- *                         are never live together); 0 = separate regions.  Set before d3pm_workspace_bytes is called.
- * D3PM_TUNE_LAT_TILE:     tile of the latency GEMM (GEMM_VARIANT 4 / auto at M <= 1536): 0 = auto (fewest rounds over the 256 CUs,
- *                         then most workgroups), 1 / 2 / 3 = always 64 x 64 / 96 x 64 / 32 x 64.  Same results.
- * D3PM_TUNE_LN_PROLOGUE:  1 = wherever the latency GEMM (64 x 64 tiles, M <= 1536 rows) runs a LayerNorm-fed projection
- *                         of a d_model = 512 block, the LayerNorm is that launch's prologue (d3pm_op_linear_lnpro); 0 (default:
- *                         measured slower) = separate LayerNorm launches.  Same results.
- * D3PM_TUNE_ROW_PANEL:    bit mask of the block's projections that run as row-panel launches (d3pm_op_linear_rowpanel) when
- *                         d_model = 512, the dtype is 16-bit and batch * canvas is a multiple of 96: 1 = self-attention
- *                         out-projection + norm2 | norm22, 2 = both cross-attention out-projections + norm3 / FiLM, 4 = fc2 +
- *                         the next block's norm1.  Default 3 (fc2 measured slower fused).  Same results as the separate launches.
- * D3PM_TUNE_GEMM_BIG_MODE: schedule of the big-tile GEMM: 1 (default) / 0 = hand-placed / compiler-placed fragment reads, 9 = the
- *                         output stores of a tile issued inside the next tile's k-steps, 513 = non-temporal output stores,
- *                         2049 = every DMA piece of a k-step issued at its top (all: same results, none faster);
- *                         timing-only builds for tests/ab_gemm.py / ab_rowpanel.py (WRONG results; bits: 16 no DMA, 32 no
- *                         MFMA, 64 no barriers, 128 no LDS reads, 256 clock stamp for d3pm_debug_gemm_clock, 4096 with 32 =
- *                         the operand stream through registers; 1025 = row panels without their LayerNorm arithmetic). */
-enum { D3PM_TUNE_GEMM_VARIANT = 0, D3PM_TUNE_ATTN_QUERY_GROUPS = 1, D3PM_TUNE_GEMM_PERSIST_SLOTS = 2,
-       D3PM_TUNE_ATTN_PAIR_SEQUENTIAL = 3, D3PM_TUNE_GEMM_BIG_MODE = 4, D3PM_TUNE_FUSED_FINAL_SAMPLE = 5,
-       D3PM_TUNE_ATTN_CROSS_RESIDENT = 6, D3PM_TUNE_GELU_TABLE = 7, D3PM_TUNE_ROW_PANEL = 8, D3PM_TUNE_LN_PROLOGUE = 9,
-       D3PM_TUNE_LAT_TILE = 10, D3PM_TUNE_WORKSPACE_ALIAS = 11 };
-int d3pm_set_tuning(int knob, int value);
-
-/* Single-op entry of the fused final projection + posterior + draw (replaces `final` at ar_discrete.py:776 followed by
- * p_sample :401-420): hidden [batch * canvas][d_model] (model dtype, already multiplied by the frame mask) -> x_next.
- * Same arguments as d3pm_posterior_sample otherwise.  D3PM_E_SHAPE when the fused kernel does not apply. */
-int d3pm_op_final_sample(const d3pm_shape *shape, const d3pm_weights *w, int batch, const void *hidden, const int32_t *x_t,
-                         int32_t *x_next, int t, const d3pm_schedule *sched, uint64_t seed, uint32_t utt0, uint32_t flags,
-                         void *stream);
-/* Diagnostic: after a big-tile GEMM launched with D3PM_TUNE_GEMM_BIG_MODE bit 8 set (and a device synchronisation),
- * {shader clocks, 100 MHz reference ticks} that workgroup 0 spent in the kernel: clocks / ticks * 100 MHz = the clock the
- * chip held under that load (MI355X_MICROARCH.md "DVFS give-back" item 6).  No output of the kernel depends on it. */
-int d3pm_debug_gemm_clock(unsigned long long* clocks_and_ticks);
-
-/* Timing hooks for bench.py's roofline object: when enabled, every launch of the kernel class
- * `kclass` (D3PM_K_*; D3PM_K_COUNT = every class) made INSIDE d3pm_sample_loop is bracketed by a hipEvent pair on
- * `stream` (in every 16th diffusion iteration only, so that the event pairs do not perturb the timed region they
- * measure; launches outside the loop -- condition encoders, cond-K/V projections -- are never bracketed).
+/* Timing hooks for bench.py's roofline object.  A d3pm_prof attached to a tuning (d3pm_tuning.prof) makes every launch of the
+ * kernel class `kclass` (D3PM_K_*; D3PM_K_COUNT = every class) made INSIDE d3pm_sample_loop with that tuning be bracketed by a
+ * hipEvent pair on the launch stream -- in every 16th diffusion iteration only, so that the event pairs do not perturb the
+ * timed region they measure; launches outside the loop (condition encoders, cond-K/V projections) are never bracketed.
  * d3pm_prof_read_class synchronises the events of one class and returns its launch count, total milliseconds and the
- * algorithmic flops / bytes of those launches; d3pm_prof_read returns the sums over the classes and resets. */
-/* D3PM_K_GEMM_LN: the launches that are a projection AND the LayerNorm(s) next to it (d3pm_op_linear_rowpanel / _lnpro) */
+ * algorithmic flops / bytes of those launches; d3pm_prof_read returns the sums over the classes and resets.  A d3pm_prof is
+ * owned by the caller (create / destroy) and must not be shared between threads that launch concurrently. */
+/* D3PM_K_GEMM_LN: the launches that are a projection AND the LayerNorm(s) next to it (d3pm_op_linear_rowpanel) */
 enum { D3PM_K_GEMM = 0, D3PM_K_ATTN = 1, D3PM_K_SAMPLE = 2, D3PM_K_LN = 3, D3PM_K_GEMM_LN = 4, D3PM_K_COUNT = 5 };
-int d3pm_prof_enable(int kclass, int max_events);
-int d3pm_prof_read_class(int kclass, int *launches, double *total_ms, double *flops, double *bytes);
-int d3pm_prof_read(int *launches, double *total_ms, double *flops, double *bytes);
-int d3pm_prof_disable(void);
+int d3pm_prof_create(int kclass, int max_events, struct d3pm_prof **out);
+int d3pm_prof_read_class(struct d3pm_prof *prof, int kclass, int *launches, double *total_ms, double *flops, double *bytes);
+int d3pm_prof_read(struct d3pm_prof *prof, int *launches, double *total_ms, double *flops, double *bytes);
+int d3pm_prof_destroy(struct d3pm_prof *prof);
 
 /* ---- Training side: gradients of the ops of AR.forward ------------------------------------------
  * The reference obtains them from autograd over ar_discrete.py:588-694 (DiT blocks :126-161, final Linear :776, masked

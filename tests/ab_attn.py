@@ -1,5 +1,5 @@
 """Timing-only ablations of the MFMA self-attention kernel (not a test): python tests/ab_attn.py
-Arms: the shipped kernel and builds with parts removed (WRONG results) -- what each part costs in place."""
+Runs on libd3pm_hip_ab.so (include/d3pm_hip_ab.h).  Arms: the shipped kernel and builds with parts removed (results wrong by construction) -- what each part costs in place."""
 import os
 import sys
 
@@ -9,8 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "tts-with-diffusion-model_amd"), ROOT]
 import __graft_entry__ as g  # noqa: E402
 
-g.build()
+g.build_ab()                       # libd3pm_hip_ab.so: the ablation arms are not in the product
 from vall_e.vall_e import _hip  # noqa: E402
+_hip.use_ab_library()
 
 DEV = "cuda:0"
 B, T, H, d = 32, 768, 8, 512
@@ -40,7 +41,10 @@ names = dict(ARMS)
 flops = 4.0 * B * H * T * T * 64
 ref = None
 for arm in arms:
-    _hip.set_attn_query_groups(arm) if arm < 100 else _hip.check(_hip.lib().d3pm_set_tuning(1, arm), "tune")
+    if arm in (1, 2):
+        _hip.set_attn_arm(0); _hip.set_attn_query_groups(arm)
+    else:
+        _hip.set_attn_query_groups(0); _hip.set_attn_arm(arm)
     if arm in (1, 2, 3, 164, 228, 201, 202):                  # the arms that must give the shipped kernel's bits
         o = _hip.op_attention(q, k, v, H, 0.125, family=_hip.FAMILY_MFMA)
         ref = o.clone() if ref is None else ref
@@ -48,3 +52,4 @@ for arm in arms:
     t = timeit(lambda: _hip.op_attention(q, k, v, H, 0.125, family=_hip.FAMILY_MFMA))
     print("%-28s %7.1f us  %6.0f TFLOP/s-equivalent" % (names.get(arm, str(arm)), t, flops / t / 1e6), flush=True)
 _hip.set_attn_query_groups(0)
+_hip.set_attn_arm(0)

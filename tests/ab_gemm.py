@@ -1,9 +1,12 @@
 """Interleaved A/B of GEMM schedules inside one process: medians over alternating repetitions.
 arguments: <variant>[m<big mode>] ...   variants: 2 = 128x128 persistent (round-1 default), 6 = 192x256 big tile,
-7 = 96x512 big tile; big modes: 0 compiler-placed reads, 1 hand-placed reads, 16 / 17 / 32 timing-only ablations."""
+7 = 96x512 big tile, 9 = the five-slab ring; big modes: 0 compiler-placed reads, 1 hand-placed reads, 16 / 17 / 32 timing-only ablations."""
 import math, statistics, sys, torch
-sys.path.insert(0, "tts-with-diffusion-model_amd")
+sys.path[:0] = ["tts-with-diffusion-model_amd", "."]
+import __graft_entry__ as g
+g.build_ab()                       # libd3pm_hip_ab.so (include/d3pm_hip_ab.h): big modes other than 1 and the ring are not in the product
 from vall_e.vall_e import _hip
+_hip.use_ab_library()
 DEV, dtype = "cuda", torch.bfloat16
 ARMS = [(int(a.split("m")[0]), int(a.split("m")[1]) if "m" in a else 1) for a in (sys.argv[1:] or ["2", "6", "7", "8", "0"])]
 
@@ -28,7 +31,7 @@ for name, M, N, K, act, res in shapes:
     outs, clocks = {}, {}
     for rep in range(7):
         for arm in ARMS:
-            _hip.set_gemm_variant(arm[0]); _hip.set_gemm_big_mode(arm[1])
+            _hip.set_gemm_ring(arm[0] == 9); _hip.set_gemm_variant(0 if arm[0] == 9 else arm[0]); _hip.set_gemm_big_mode(arm[1])
             res_t[arm].append(timeit(f))
             if arm[1] & 256 and rep == 6:
                 clocks[arm] = _hip.gemm_clock_ghz()
@@ -41,4 +44,4 @@ for name, M, N, K, act, res in shapes:
         t = statistics.median(res_t[arm])
         line += f" | v{arm[0]}m{arm[1]}: {t:6.1f} us {2 * M * N * K / t / 1e6:6.0f} TF/s" + (f" @{clocks[arm]:.2f} GHz" if arm in clocks else "")
     print(line + f" | bit-identical: {same}", flush=True)
-_hip.set_gemm_variant(0); _hip.set_gemm_big_mode(1)
+_hip.set_gemm_variant(0); _hip.set_gemm_big_mode(1); _hip.set_gemm_ring(False)

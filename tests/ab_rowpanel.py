@@ -1,7 +1,10 @@
 """Timing of the row-panel launches against the launches they replace (not a test): python tests/ab_rowpanel.py"""
 import math, statistics, sys, torch
-sys.path.insert(0, "tts-with-diffusion-model_amd")
+sys.path[:0] = ["tts-with-diffusion-model_amd", "."]
+import __graft_entry__ as g
+g.build_ab()                       # libd3pm_hip_ab.so: the no-LayerNorm timing build is not in the product
 from vall_e.vall_e import _hip
+_hip.use_ab_library()
 DEV, dtype = "cuda", torch.bfloat16
 M, K = 24576, 512
 g = torch.Generator(device="cpu").manual_seed(0)

@@ -40,7 +40,38 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in declared:
         assert hasattr(built_lib, name), name
     from vall_e.vall_e import _hip as _h
-    assert built_lib.d3pm_abi_version() == _h.ABI_VERSION == 3
+    assert built_lib.d3pm_abi_version() == _h.ABI_VERSION == 4
+
+
+def test_product_library_holds_no_experiments_and_no_tuning_state(built_lib):
+    """VERDICT round 2 / ADVICE: the timing-only ablation builds (wrong results by construction) and the process-wide
+    d3pm_set_tuning are gone from libd3pm_hip.so.  What is left of them lives in libd3pm_hip_ab.so (include/d3pm_hip_ab.h),
+    which only tests/ab_*.py load; the product's schedule choices travel in d3pm_tuning, a plain struct the caller owns."""
+    import ctypes as C
+    from vall_e.vall_e import _hip
+    ab_header = open(os.path.join(ROOT, "include", "d3pm_hip_ab.h")).read()
+    ab_only = set(re.findall(r"\b(d3pm_[a-z_0-9]+)\s*\(", ab_header)) - {"d3pm_hip"}
+    assert ab_only == set(_hip.AB_SIGNATURES), ab_only ^ set(_hip.AB_SIGNATURES)
+    for name in ab_only | {"d3pm_set_tuning"}:
+        assert not hasattr(built_lib, name), f"{name} is exported by the product library"
+    header = open(os.path.join(ROOT, "include", "d3pm_hip.h")).read()
+    assert "WRONG" not in header and "d3pm_set_tuning(" not in header.replace("(d3pm_set_tuning)", "")
+    # the kernels of the experiments are not even in the code object: no ablation / ring / fused-final instantiation
+    lib_bytes = open(_hip.LIB_PATH, "rb").read()
+    for marker in (b"gemm_mfma_ring", b"final_sample_fused", b"fill_gelu_table"):
+        assert marker not in lib_bytes, marker
+    # defaults come from the library and a tuning is a value: two of them are independent
+    a, b = _hip.Tuning(), _hip.Tuning()
+    built_lib.d3pm_tuning_default(C.byref(a))
+    built_lib.d3pm_tuning_default(C.byref(b))
+    b.gemm_variant = 5
+    assert (a.gemm_variant, a.gemm_persist_slots, a.row_panel, a.workspace_alias, a.attn_cross_resident) == (0, 1024, 3, 1, 1)
+    # workspace_alias is read from the shape's tuning, not from a global
+    from vall_e.vall_e import synth
+    cfg = synth.D3PMConfig.libritts()
+    sh_a, sh_b = _hip.make_shape(cfg, torch.bfloat16, a), _hip.make_shape(cfg, torch.bfloat16, b)
+    b.workspace_alias = 0
+    assert built_lib.d3pm_workspace_bytes(C.byref(sh_b), 4) > built_lib.d3pm_workspace_bytes(C.byref(sh_a), 4) > 0
 
 
 @pytest.mark.parametrize("timesteps", [100, 200])

@@ -1,4 +1,4 @@
-# A/B of d3pm_set_tuning overrides on the headline workload: bash tools/ab_tune.sh "8=0" "8=1" ...   (one bench line per arm)
+# A/B of d3pm_tuning fields on the headline workload: bash tools/ab_tune.sh "row_panel=0" "row_panel=3" ...   (one bench line per arm)
 : "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 for arm in "$@"; do
   tag=$(echo "$arm" | tr ',=' '__')

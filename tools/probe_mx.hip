@@ -134,5 +134,29 @@ int main() {
   std::fill(SB.begin(), SB.end(), 0x7f808182);
   run(dv, A, B, SA, SB, 0, 1, D);
   printf("exp7 op_sel_b = 1: D = %g (expect 512)\n", D[0][0]);
+  std::fill(SB.begin(), SB.end(), 127);
+  // experiment 8: byte-level map.  For operand lane L = (row r, group g) and byte b: which scale lane r + 16 q (q = 0..3) scales it
+  std::fill(B.begin(), B.end(), e4m3(1));
+  for (int which = 0; which < 2; ++which)
+    for (int L : {3, 19, 35, 51}) {
+      printf("exp8 %c lane %2d (row %d, group %d): scale group of byte 0..31 = ", which ? 'B' : 'A', L, L & 15, L >> 4);
+      for (int b = 0; b < 32; ++b) {
+        std::vector<uint8_t>& OP = which ? B : A;
+        std::vector<uint8_t>& OTHER = which ? A : B;
+        std::fill(OTHER.begin(), OTHER.end(), e4m3(1));
+        std::fill(OP.begin(), OP.end(), 0);
+        OP[L * 32 + b] = e4m3(1);
+        int found = -1;
+        for (int q = 0; q < 4; ++q) {
+          std::fill(SA.begin(), SA.end(), 127); std::fill(SB.begin(), SB.end(), 127);
+          (which ? SB : SA)[(L & 15) + 16 * q] = 128;
+          run(dv, A, B, SA, SB, 0, 0, D);
+          float mx_ = 0; for (int l = 0; l < 64; ++l) for (int r = 0; r < 4; ++r) mx_ = D[l][r] > mx_ ? D[l][r] : mx_;
+          if (mx_ == 2.f) found = q;
+        }
+        printf("%d", found);
+      }
+      printf("\n");
+    }
   return 0;
 }

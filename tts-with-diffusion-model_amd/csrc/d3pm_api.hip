@@ -7,9 +7,13 @@
 // Nothing here allocates or synchronises; everything is enqueued on the caller's stream.
 #include <cstdarg>
 #include <cstdio>
+#include <new>
 #include <vector>
 
 #include "d3pm_kernels.h"
+#ifdef D3PM_ABLATIONS
+#include "../../include/d3pm_hip_ab.h"
+#endif
 
 namespace d3pm {
 
@@ -25,32 +29,25 @@ int q_sample_launch(const d3pm_shape*, int, const int32_t*, int32_t*, const uint
                     uint64_t, uint32_t, hipStream_t);
 int uniform_launch(uint64_t, int, uint32_t, int, int, int, float*, hipStream_t);
 int ce_loss_launch(int, const void*, int, const int32_t*, const uint8_t*, int, int, int, float*, hipStream_t);
-void set_gemm_variant(int v);
-void set_gemm_persist_slots(int v);
-void set_attn_pair_sequential(int v);
-void set_attn_qg(int v);
-void set_lat_tile(int v);
-void set_attn_cross_resident(int v);
-void set_gelu_table(int v);
-void set_big_gemm_mode(int v);
+#ifdef D3PM_ABLATIONS
 bool final_sample_supported(int dtype, int n_classes, int d, const void* X, int ldx, const void* W);
 int final_sample(int dtype, const void* X, int ldx, const void* W, const void* bias, int d, const SampleArgs& a, hipStream_t s);
-// D3PM_TUNE_FUSED_FINAL_SAMPLE.  Off by default: measured on MI355X (B = 32, bf16) the fused kernel takes 253 us per
-// iteration against 32 + 90 us for the two launches -- the draw is VALU-issue-bound (~1800 vector instructions per row and
-// lane: Philox, three logf, expf, a division, the fp16 rounding points) and wants 8 waves per SIMD, the fused kernel's 66 KB
-// logits image allows 2
-static int g_fused_final_sample = 0;
-// D3PM_TUNE_ROW_PANEL: projections onto the residual stream normalise their rows in the epilogue (d3pm_mfma_gemm_big.hip)
-// measured on the bench workload (tools/ab_tune.sh, profiles/round2_c_ab_throughput.txt): 1 | 2 gains 0.9 %; fc2 (4) loses -- its
-// K = 2048 product runs 30 us slower on 96 x 512 tiles than on 192 x 256, more than the norm1 launch it saves
-static int g_row_panel = 3;
 int read_big_gemm_stamp(unsigned long long* out);
+// libd3pm_hip_ab.so only: the knobs of the experiments (include/d3pm_hip_ab.h).  Process-wide on purpose -- an A/B script toggles
+// them between interleaved arms; the product library does not contain this object.
+AbKnobs& ab_knobs() {
+  static AbKnobs k;
+  return k;
+}
+#endif
 
-// ---- profiling hooks (bench.py roofline object) ----------------------------------------------
+}  // namespace d3pm
+
+// ---- profiling hooks (bench.py roofline object): a caller-owned handle, reached through d3pm_tuning.prof -----------------------
 // Only launches made from inside d3pm_sample_loop are ever bracketed (sample_now is false outside it): the condition
 // encoders and the cond-K/V projections run once per utterance and are not part of any class's per-launch figures.
-struct Prof {
-  int kclass = -1;                // -1 off, D3PM_K_* one class, D3PM_K_COUNT every class
+struct d3pm_prof {
+  int kclass = -1;                // D3PM_K_* one class, D3PM_K_COUNT every class
   std::vector<hipEvent_t> ev;     // pairs
   std::vector<int> cls;           // class of pair i
   int used = 0;
@@ -58,57 +55,77 @@ struct Prof {
   int stride = 16;       // only the iterations with t % stride == 0 are bracketed (event pairs cost ~3 us each: all launches 6 % of the step, every 8th 2.5 %)
   bool sample_now = false;
 };
-static Prof g_prof;
+
+namespace d3pm {
+
+// what a launch sequence carries besides its arguments: the caller's schedule choices and (optionally) its timing hooks
+struct Ctx {
+  const d3pm_tuning* tune;
+  d3pm_prof* prof;
+  explicit Ctx(const d3pm_tuning* t) : tune(t), prof(t ? t->prof : nullptr) {}
+};
 
 struct ProfScope {
   bool on;
+  d3pm_prof* p;
   hipStream_t s;
-  ProfScope(int kclass, hipStream_t st, double flops, double bytes) : s(st) {
-    on = (g_prof.kclass == kclass || g_prof.kclass == D3PM_K_COUNT) && g_prof.sample_now &&
-         g_prof.used + 2 <= static_cast<int>(g_prof.ev.size());
+  ProfScope(const Ctx& cx, int kclass, hipStream_t st, double flops, double bytes) : p(cx.prof), s(st) {
+    on = p && (p->kclass == kclass || p->kclass == D3PM_K_COUNT) && p->sample_now && p->used + 2 <= static_cast<int>(p->ev.size());
     if (on) {
-      (void)hipEventRecord(g_prof.ev[g_prof.used], s);
-      g_prof.cls[g_prof.used / 2] = kclass;
-      g_prof.flops[kclass] += flops;
-      g_prof.bytes[kclass] += bytes;
+      (void)hipEventRecord(p->ev[p->used], s);
+      p->cls[p->used / 2] = kclass;
+      p->flops[kclass] += flops;
+      p->bytes[kclass] += bytes;
     }
   }
   ~ProfScope() {
     if (on) {
-      (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
-      g_prof.used += 2;
+      (void)hipEventRecord(p->ev[p->used + 1], s);
+      p->used += 2;
     }
   }
 };
 
 // ---- kernel-family dispatch ----------------------------------------------------------------
-static int run_linear(int dtype, const LinearArgs& a, uint32_t flags, hipStream_t s) {
+static int run_linear(const Ctx& cx, int dtype, LinearArgs a, uint32_t flags, hipStream_t s) {
   const size_t es = dtype_size(dtype);
-  ProfScope p(D3PM_K_GEMM, s, 2.0 * a.M * a.N * a.K,
+  a.tune = cx.tune;
+  ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * a.M * a.N * a.K,
               es * (static_cast<double>(a.M) * a.K + static_cast<double>(a.N) * a.K +
                     static_cast<double>(a.M) * a.N * (1 + (a.R1 ? 1 : 0) + (a.R2 ? 1 : 0))));
   if (!(flags & D3PM_FLAG_FORCE_GENERIC) && mfma_linear_supported(dtype, a)) return mfma_linear(dtype, a, s);
   return generic_linear(dtype, a, s);
 }
-// D3PM_TUNE_LN_PROLOGUE: at one or two utterances the LayerNorm-fed projections normalise their operand rows themselves
-static int g_ln_prologue = 0;
+#ifdef D3PM_ABLATIONS
+// D3PM_AB_LN_PROLOGUE: at one or two utterances the LayerNorm-fed projections normalise their operand rows themselves.
 // LayerNorm + projection in one launch of the latency GEMM (d3pm_mfma_gemm_lat.hip); a.X is the un-normalised stream
-static int run_ln_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, hipStream_t s) {
+static int run_ln_linear(const Ctx& cx, int dtype, LinearArgs a, const LnPrologue& ln, hipStream_t s) {
   const size_t es = dtype_size(dtype);
-  ProfScope p(D3PM_K_GEMM_LN, s, 2.0 * a.M * a.N * a.K,
+  a.tune = cx.tune;
+  ProfScope p(cx, D3PM_K_GEMM_LN, s, 2.0 * a.M * a.N * a.K,
               es * (static_cast<double>(ln.period ? ln.period : a.M) * a.K + static_cast<double>(a.N) * a.K + static_cast<double>(a.M) * a.N));
   return ln_prologue_linear(dtype, a, ln, s);
 }
+static bool ln_prologue_applies(const Ctx& cx, int dtype, LinearArgs a, const LnPrologue& ln) {
+  a.tune = cx.tune;
+  return ln_prologue_linear_applies(dtype, a, ln);
+}
+#else
+// the LayerNorm-prologue form of the latency GEMM was measured slower and lives in libd3pm_hip_ab.so only (include/d3pm_hip_ab.h)
+static int run_ln_linear(const Ctx&, int, const LinearArgs&, const LnPrologue&, hipStream_t) { return D3PM_E_SHAPE; }
+static bool ln_prologue_applies(const Ctx&, int, const LinearArgs&, const LnPrologue&) { return false; }
+#endif
 // projection onto the residual stream + the LayerNorm(s) of the new rows, one launch (d3pm_mfma_gemm_big.hip)
-static int run_row_panel(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s) {
+static int run_row_panel(const Ctx& cx, int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s) {
   const size_t es = dtype_size(dtype);
   const double prods = f.X2 ? 2.0 : 1.0, mn = static_cast<double>(a.M) * a.N;
-  ProfScope p(D3PM_K_GEMM_LN, s, prods * 2.0 * a.M * a.N * a.K,
+  ProfScope p(cx, D3PM_K_GEMM_LN, s, prods * 2.0 * a.M * a.N * a.K,
               es * (prods * a.M * a.K + static_cast<double>(a.N) * a.K + mn * (3.0 + (f.lny2 ? 1.0 : 0.0))));
   return row_panel_linear(dtype, a, f, s);
 }
-static int run_attention(int dtype, const AttnArgs& a, uint32_t flags, hipStream_t s) {
-  ProfScope p(D3PM_K_ATTN, s, 4.0 * a.B * a.H * a.Tq * static_cast<double>(a.S + a.S2) * a.hd,
+static int run_attention(const Ctx& cx, int dtype, AttnArgs a, uint32_t flags, hipStream_t s) {
+  a.tune = cx.tune;
+  ProfScope p(cx, D3PM_K_ATTN, s, 4.0 * a.B * a.H * a.Tq * static_cast<double>(a.S + a.S2) * a.hd,
               dtype_size(dtype) * (2.0 * a.B * a.Tq * a.H * a.hd + 2.0 * a.B * (a.S + a.S2) * a.H * a.hd));
   if (!(flags & D3PM_FLAG_FORCE_GENERIC) && mfma_attention_supported(dtype, a)) return mfma_attention(dtype, a, s);
   if (a.Q2) {   // the generic kernel takes one problem per launch
@@ -121,14 +138,13 @@ static int run_attention(int dtype, const AttnArgs& a, uint32_t flags, hipStream
   }
   return generic_attention(dtype, a, s);
 }
-static int run_layernorm(int dtype, const LayerNormArgs& a, uint32_t flags, hipStream_t s) {
-  ProfScope p(D3PM_K_LN, s, 0.0, dtype_size(dtype) * static_cast<double>(a.M) * a.d * (a.Y2 ? 3.0 : 2.0));
+static int run_layernorm(const Ctx& cx, int dtype, const LayerNormArgs& a, uint32_t flags, hipStream_t s) {
+  ProfScope p(cx, D3PM_K_LN, s, 0.0, dtype_size(dtype) * static_cast<double>(a.M) * a.d * (a.Y2 ? 3.0 : 2.0));
   if (!(flags & D3PM_FLAG_FORCE_GENERIC) && fast_layernorm_supported(dtype, a)) return fast_layernorm(dtype, a, s);
   return generic_layernorm(dtype, a, s);
 }
 
 // ---- workspace carve-up ----------------------------------------------------------------------
-static int g_ws_alias = 1;
 struct Workspace {
   char *x, *h, *h2, *qkv, *att, *att2, *mlp, *logits;
   size_t total;
@@ -148,7 +164,7 @@ static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
   // 256-MB Infinity Cache, +1.6 % tokens/s measured for the first pair alone (profiles/round2_c_ab_throughput.txt):
   //   packed qkv rows -> cross-attention queries -> MLP hidden rows -> logits of the iteration;
   //   norm22 output (dead once the query projection ran) -> prompt cross-attention output
-  if (g_ws_alias) {
+  if (tune_of(sh.tuning).workspace_alias) {
     const size_t big = n * 4 * d * es, lg = n * logits_ld(sh) * es;
     w.mlp = take(big > lg ? big : lg);
     w.qkv = w.mlp;
@@ -193,6 +209,7 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
                            const d3pm_fp8_block_weights* f8 = nullptr) {
   const int dt = sh.dtype, d = sh.d_model, H = sh.n_heads, hd = d / H, T = sh.canvas;
   const int n = batch * T;
+  const Ctx cx(sh.tuning);
   // fp8 fast path (BASELINE.json configs[4]): the three LayerNorm-fed K = d projections take e4m3 operands; the e4m3 rows
   // and their scales live where the 16-bit LayerNorm outputs would (ws.h | ws.h2 are adjacent: 2 n d 2 bytes)
   const bool use8 = f8 != nullptr;
@@ -217,7 +234,7 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     ln0.X = w.resps_emb; ln0.Y = ws.h; ln0.w = w.blocks[0].norm1_w; ln0.b = w.blocks[0].norm1_b; ln0.M = n; ln0.d = d; ln0.eps = 1e-6f;
     ln0.tokens = x_t; ln0.frame_mask = frame_mask; ln0.canvas = T; ln0.n_classes = sh.n_classes; ln0.Xout = ws.x;
     if (fast_layernorm_supported(dt, ln0)) {
-      ProfScope p(D3PM_K_LN, s, 0.0, dtype_size(dt) * static_cast<double>(n) * d * 3.0);
+      ProfScope p(cx, D3PM_K_LN, s, 0.0, dtype_size(dt) * static_cast<double>(n) * d * 3.0);
       D3PM_TRY(fast_layernorm(dt, ln0, s));
       embed_fused = true;
     }
@@ -229,10 +246,15 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
   // (one 96-row tile per workgroup: only when the tiles fill >= 85 % of whole rounds over the 256 CUs, as for the other big tiles)
   const long long rp_tiles = n / 96, rp_rounds = (rp_tiles + 255) / 256;
   const bool rp_fills = n % 96 == 0 && rp_tiles * 5 >= 256 * 4 && rp_tiles * 100 >= rp_rounds * 256 * 85;
-  const int panel = (!use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && rp_fills && (dt == D3PM_F16 || dt == D3PM_BF16)) ? g_row_panel : 0;
+  const int panel = (!use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && rp_fills && (dt == D3PM_F16 || dt == D3PM_BF16)) ? (tune_of(sh.tuning).row_panel & 7) : 0;
   bool norm1_done = embed_fused;   // norm1(x) of this block is already in ws.h (the embedding launch, or the previous block's fc2)
   // the opposite regime (one or two utterances, latency GEMM): LayerNorm runs as the prologue of the projection it feeds
-  const bool lnpro = g_ln_prologue && !use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && (dt == D3PM_F16 || dt == D3PM_BF16);
+#ifdef D3PM_ABLATIONS
+  const bool lnpro_on = ab_knobs().ln_prologue != 0;
+#else
+  const bool lnpro_on = false;
+#endif
+  const bool lnpro = lnpro_on && !use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && (dt == D3PM_F16 || dt == D3PM_BF16);
 
   for (int l = 0; l < layers; ++l) {
     const d3pm_block_weights& b = w.blocks[l];
@@ -244,7 +266,7 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     g.M = n; g.N = 3 * d; g.K = d;
     if (use8) {
       D3PM_TRY(layernorm_fp8(dt, ws.x, x8, sx8, b.norm1_w, b.norm1_b, nullptr, nullptr, nullptr, nullptr, nullptr, n, d, 1e-6f, s));
-      ProfScope p(D3PM_K_GEMM, s, 2.0 * g.M * g.N * g.K, 1.0 * g.M * g.K + 1.0 * g.N * g.K + es * g.M * g.N);
+      ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * g.M * g.N * g.K, 1.0 * g.M * g.K + 1.0 * g.N * g.K + es * g.M * g.N);
       D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].attn_in_w8), f8[l].attn_in_scale, b.attn_in_b, ws.qkv,
                           3 * d, n, 3 * d, d, ACT_NONE, s));
     } else {
@@ -252,18 +274,18 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       lp.w = ln.w; lp.b = ln.b; lp.eps = ln.eps;
       LinearArgs gx = g;
       gx.X = ws.x;
-      if (!norm1_done && lnpro && ln_prologue_linear_applies(dt, gx, lp)) {
-        D3PM_TRY(run_ln_linear(dt, gx, lp, s));
+      if (!norm1_done && lnpro && ln_prologue_applies(cx, dt, gx, lp)) {
+        D3PM_TRY(run_ln_linear(cx, dt, gx, lp, s));
       } else {
-        if (!norm1_done) D3PM_TRY(run_layernorm(dt, ln, flags, s));
-        D3PM_TRY(run_linear(dt, g, flags, s));
+        if (!norm1_done) D3PM_TRY(run_layernorm(cx, dt, ln, flags, s));
+        D3PM_TRY(run_linear(cx, dt, g, flags, s));
       }
     }
     norm1_done = false;
     AttnArgs a;
     a.Q = ws.qkv; a.ldq = 3 * d; a.K = at(ws.qkv, d, es); a.V = at(ws.qkv, 2 * d, es); a.ldkv = 3 * d;
     a.O = ws.att; a.ldo = d; a.B = batch; a.Tq = T; a.S = T; a.H = H; a.hd = hd; a.scale = scale;
-    D3PM_TRY(run_attention(dt, a, flags, s));
+    D3PM_TRY(run_attention(cx, dt, a, flags, s));
     g = LinearArgs();
     g.X = ws.att; g.ldx = d; g.W = b.attn_out_w; g.bias = b.attn_out_b; g.Y = ws.x; g.ldy = d;
     g.R1 = ws.x; g.ldr = d; g.M = n; g.N = d; g.K = d;
@@ -274,15 +296,15 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     RowPanelFuse rp;
     rp.lnw = ln.w; rp.lnb = ln.b; rp.lny = ln.Y; rp.lnw2 = ln.w2; rp.lnb2 = ln.b2; rp.lny2 = ln.Y2; rp.eps = ln.eps;
     const bool norm2_fused = (panel & 1) && row_panel_supported(dt, g, rp);
-    if (norm2_fused) D3PM_TRY(run_row_panel(dt, g, rp, s));
-    else D3PM_TRY(run_linear(dt, g, flags, s));
+    if (norm2_fused) D3PM_TRY(run_row_panel(cx, dt, g, rp, s));
+    else D3PM_TRY(run_linear(cx, dt, g, flags, s));
     char* q_text = ws.qkv;
     char* q_prom = at(ws.qkv, static_cast<size_t>(n) * d, es);
     if (use8) {
       // e4m3 rows of norm2(x) | norm22(x) stacked [2n][d] (fills ws.h), scales [2n] at ws.h2: ONE fp8 GEMM for both queries
       D3PM_TRY(layernorm_fp8(dt, ws.x, x8, sx8, b.norm2_w, b.norm2_b, nullptr, b.norm22_w, b.norm22_b,
                              x8 + static_cast<size_t>(n) * d, sx8 + n, n, d, 1e-6f, s));
-      ProfScope p(D3PM_K_GEMM, s, 2.0 * 2 * n * d * d, 2.0 * n * d + 1.0 * d * d + es * 2.0 * n * d);
+      ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * 2 * n * d * d, 2.0 * n * d + 1.0 * d * d + es * 2.0 * n * d);
       D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].cross_in_w8), f8[l].cross_in_scale, b.cross_in_b,
                           q_text, d, 2 * n, d, d, ACT_NONE, s));
     } else if (ws.h2 == at(ws.h, static_cast<size_t>(n) * d, es)) {
@@ -294,19 +316,19 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       lp.w = ln.w; lp.b = ln.b; lp.w2 = ln.w2; lp.b2 = ln.b2; lp.eps = ln.eps; lp.period = n;
       LinearArgs gx = g;
       gx.X = ws.x;
-      if (!norm2_fused && lnpro && ln_prologue_linear_applies(dt, gx, lp)) {
-        D3PM_TRY(run_ln_linear(dt, gx, lp, s));
+      if (!norm2_fused && lnpro && ln_prologue_applies(cx, dt, gx, lp)) {
+        D3PM_TRY(run_ln_linear(cx, dt, gx, lp, s));
       } else {
-        if (!norm2_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
-        D3PM_TRY(run_linear(dt, g, flags, s));
+        if (!norm2_fused) D3PM_TRY(run_layernorm(cx, dt, ln, flags, s));
+        D3PM_TRY(run_linear(cx, dt, g, flags, s));
       }
     } else {
-      if (!norm2_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
+      if (!norm2_fused) D3PM_TRY(run_layernorm(cx, dt, ln, flags, s));
       for (int which = 0; which < 2; ++which) {
         g = LinearArgs();
         g.X = which ? ws.h2 : ws.h; g.ldx = d; g.W = b.cross_in_w; g.bias = b.cross_in_b;
         g.Y = which ? q_prom : q_text; g.ldy = d; g.M = n; g.N = d; g.K = d;
-        D3PM_TRY(run_linear(dt, g, flags, s));
+        D3PM_TRY(run_linear(cx, dt, g, flags, s));
       }
     }
     {   // text and prompt cross-attention are independent: one paired launch
@@ -316,7 +338,7 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       a.Q = q_text; a.ldq = d; a.K = kvt; a.V = at(kvt, d, es); a.ldkv = 2 * d; a.O = ws.att; a.ldo = d;
       a.B = batch; a.Tq = T; a.S = sh.s_text; a.H = H; a.hd = hd; a.scale = scale;
       a.Q2 = q_prom; a.K2 = kvp; a.V2 = at(kvp, d, es); a.O2 = ws.att2; a.S2 = sh.s_prompt;
-      D3PM_TRY(run_attention(dt, a, flags, s));
+      D3PM_TRY(run_attention(cx, dt, a, flags, s));
     }
     // ---- both out-projections, then the FiLM-modulated MLP ----
     ln = LayerNormArgs();
@@ -329,23 +351,23 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     rp.X2 = ws.att2; rp.lnw = ln.w; rp.lnb = ln.b; rp.lny = ln.Y; rp.film = ln.film; rp.eps = ln.eps;
     const bool norm3_fused = (panel & 2) && row_panel_supported(dt, g, rp);
     if (norm3_fused) {
-      D3PM_TRY(run_row_panel(dt, g, rp, s));
+      D3PM_TRY(run_row_panel(cx, dt, g, rp, s));
     } else {
       // o_text -> h (free now); x = (x + o_text) + o_prompt, rounded at each add like the eager sum
       g = LinearArgs();
       g.X = ws.att; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.h; g.ldy = d; g.M = n; g.N = d; g.K = d;
-      D3PM_TRY(run_linear(dt, g, flags, s));
+      D3PM_TRY(run_linear(cx, dt, g, flags, s));
       g = LinearArgs();
       g.X = ws.att2; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.x; g.ldy = d;
       g.R1 = ws.x; g.R2 = ws.h; g.ldr = d; g.M = n; g.N = d; g.K = d;
-      D3PM_TRY(run_linear(dt, g, flags, s));
+      D3PM_TRY(run_linear(cx, dt, g, flags, s));
     }
     g = LinearArgs();
     g.X = ws.h; g.ldx = d; g.W = b.fc1_w; g.bias = b.fc1_b; g.Y = ws.mlp; g.ldy = 4 * d; g.M = n; g.N = 4 * d; g.K = d;
     g.act = ACT_GELU;
     if (use8) {
       D3PM_TRY(layernorm_fp8(dt, ws.x, x8, sx8, b.norm3_w, b.norm3_b, ln.film, nullptr, nullptr, nullptr, nullptr, n, d, 1e-6f, s));
-      ProfScope p(D3PM_K_GEMM, s, 2.0 * g.M * g.N * g.K, 1.0 * g.M * g.K + 1.0 * g.N * g.K + es * g.M * g.N);
+      ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * g.M * g.N * g.K, 1.0 * g.M * g.K + 1.0 * g.N * g.K + es * g.M * g.N);
       D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].fc1_w8), f8[l].fc1_scale, b.fc1_b, ws.mlp, 4 * d, n,
                           4 * d, d, ACT_GELU, s));
     } else {
@@ -353,11 +375,11 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
       lp.w = ln.w; lp.b = ln.b; lp.film = ln.film; lp.eps = ln.eps;
       LinearArgs gx = g;
       gx.X = ws.x;
-      if (!norm3_fused && lnpro && ln_prologue_linear_applies(dt, gx, lp)) {
-        D3PM_TRY(run_ln_linear(dt, gx, lp, s));
+      if (!norm3_fused && lnpro && ln_prologue_applies(cx, dt, gx, lp)) {
+        D3PM_TRY(run_ln_linear(cx, dt, gx, lp, s));
       } else {
-        if (!norm3_fused) D3PM_TRY(run_layernorm(dt, ln, flags, s));
-        D3PM_TRY(run_linear(dt, g, flags, s));
+        if (!norm3_fused) D3PM_TRY(run_layernorm(cx, dt, ln, flags, s));
+        D3PM_TRY(run_linear(cx, dt, g, flags, s));
       }
     }
     g = LinearArgs();
@@ -366,10 +388,10 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     rp = RowPanelFuse();
     if (l + 1 < layers) { rp.lnw = w.blocks[l + 1].norm1_w; rp.lnb = w.blocks[l + 1].norm1_b; rp.lny = ws.h; rp.eps = 1e-6f; }
     if ((panel & 4) && l + 1 < layers && row_panel_supported(dt, g, rp)) {
-      D3PM_TRY(run_row_panel(dt, g, rp, s));
+      D3PM_TRY(run_row_panel(cx, dt, g, rp, s));
       norm1_done = true;
     } else {
-      D3PM_TRY(run_linear(dt, g, flags, s));
+      D3PM_TRY(run_linear(cx, dt, g, flags, s));
     }
   }
   return D3PM_OK;
@@ -377,8 +399,12 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
 
 // the fused final + sampler kernel takes over wherever the final projection would have run on the MFMA family
 static bool fused_final_sample_applies(const d3pm_shape& sh, const d3pm_weights& w, const Workspace& ws, uint32_t flags) {
-  return g_fused_final_sample && !(flags & D3PM_FLAG_FORCE_GENERIC) && sh.d_model >= 64 &&
+#ifdef D3PM_ABLATIONS
+  return ab_knobs().fused_final_sample && !(flags & D3PM_FLAG_FORCE_GENERIC) && sh.d_model >= 64 &&
          final_sample_supported(sh.dtype, sh.n_classes, sh.d_model, ws.x, sh.d_model, w.final_w);
+#else
+  return false;      // built, bit-identical, 253 us vs 30 + 87 us: lives in libd3pm_hip_ab.so only (include/d3pm_hip_ab.h)
+#endif
 }
 
 static int final_logits(const d3pm_shape& sh, const d3pm_weights& w, int batch, const Workspace& ws, void* logits,
@@ -387,7 +413,8 @@ static int final_logits(const d3pm_shape& sh, const d3pm_weights& w, int batch, 
   LinearArgs g;
   g.X = ws.x; g.ldx = sh.d_model; g.W = w.final_w; g.bias = w.final_b; g.Y = logits; g.ldy = ldl;
   g.M = batch * sh.canvas; g.N = sh.n_classes; g.K = sh.d_model;
-  return run_linear(sh.dtype, g, flags, s);
+  const Ctx cx(sh.tuning);
+  return run_linear(cx, sh.dtype, g, flags, s);
 }
 
 }  // namespace d3pm
@@ -424,6 +451,7 @@ int d3pm_cond_kv(const d3pm_shape* sh, const d3pm_weights* w, int batch, const v
   D3PM_REQUIRE(w && w->blocks && cond_text && cond_prompt && kv_text && kv_prompt, D3PM_E_ARG, "d3pm_cond_kv: null pointer");
   const int d = sh->d_model;
   const size_t es = dtype_size(sh->dtype);
+  const Ctx cx(sh->tuning);
   for (int l = 0; l < sh->n_layers; ++l)
     for (int which = 0; which < 2; ++which) {
       const int S = which ? sh->s_prompt : sh->s_text;
@@ -433,7 +461,7 @@ int d3pm_cond_kv(const d3pm_shape* sh, const d3pm_weights* w, int batch, const v
       g.bias = at(w->blocks[l].cross_in_b, d, es);
       g.Y = at(which ? kv_prompt : kv_text, static_cast<size_t>(l) * batch * S * 2 * d, es); g.ldy = 2 * d;
       g.M = batch * S; g.N = 2 * d; g.K = d;
-      D3PM_TRY(run_linear(sh->dtype, g, 0, static_cast<hipStream_t>(stream)));
+      D3PM_TRY(run_linear(cx, sh->dtype, g, 0, static_cast<hipStream_t>(stream)));
     }
   return D3PM_OK;
 }
@@ -462,37 +490,38 @@ static int run_encoder(const d3pm_shape& sh, const d3pm_encoder_weights& e, int 
                        hipStream_t s) {
   const int dt = sh.dtype, d = sh.d_model, n = batch * seq, hd = d / e.n_heads;
   const size_t es = dtype_size(dt);
+  const Ctx cx(sh.tuning);
   for (int l = 0; l < e.n_layers; ++l) {
     const d3pm_encoder_layer_weights& w = e.layers[l];
     LinearArgs g;
     g.X = ws.x; g.ldx = d; g.W = w.in_w; g.bias = w.in_b; g.Y = ws.qkv; g.ldy = 3 * d; g.M = n; g.N = 3 * d; g.K = d;
-    D3PM_TRY(run_linear(dt, g, 0, s));
+    D3PM_TRY(run_linear(cx, dt, g, 0, s));
     AttnArgs a;
     a.Q = ws.qkv; a.ldq = 3 * d; a.K = at(ws.qkv, d, es); a.V = at(ws.qkv, 2 * d, es); a.ldkv = 3 * d; a.O = ws.att; a.ldo = d;
     a.B = batch; a.Tq = seq; a.S = seq; a.H = e.n_heads; a.hd = hd; a.scale = static_cast<float>(std::sqrt(1.0 / hd));
-    D3PM_TRY(run_attention(dt, a, 0, s));
+    D3PM_TRY(run_attention(cx, dt, a, 0, s));
     g = LinearArgs();   // x + self_attn(x), then post-norm
     g.X = ws.att; g.ldx = d; g.W = w.out_w; g.bias = w.out_b; g.Y = ws.tmp; g.ldy = d; g.R1 = ws.x; g.ldr = d; g.M = n; g.N = d; g.K = d;
-    D3PM_TRY(run_linear(dt, g, 0, s));
+    D3PM_TRY(run_linear(cx, dt, g, 0, s));
     LayerNormArgs ln;
     ln.X = ws.tmp; ln.Y = ws.x; ln.w = w.norm1_w; ln.b = w.norm1_b; ln.M = n; ln.d = d; ln.eps = 1e-5f;
-    D3PM_TRY(run_layernorm(dt, ln, 0, s));
+    D3PM_TRY(run_layernorm(cx, dt, ln, 0, s));
     g = LinearArgs();   // FFN: linear2(relu(linear1(x)))
     g.X = ws.x; g.ldx = d; g.W = w.lin1_w; g.bias = w.lin1_b; g.Y = ws.ff; g.ldy = e.d_ff; g.M = n; g.N = e.d_ff; g.K = d; g.act = ACT_RELU;
-    D3PM_TRY(run_linear(dt, g, 0, s));
+    D3PM_TRY(run_linear(cx, dt, g, 0, s));
     g = LinearArgs();
     g.X = ws.ff; g.ldx = e.d_ff; g.W = w.lin2_w; g.bias = w.lin2_b; g.Y = ws.tmp; g.ldy = d; g.R1 = ws.x; g.ldr = d; g.M = n; g.N = d; g.K = e.d_ff;
-    D3PM_TRY(run_linear(dt, g, 0, s));
+    D3PM_TRY(run_linear(cx, dt, g, 0, s));
     ln = LayerNormArgs();
     ln.X = ws.tmp; ln.Y = ws.x; ln.w = w.norm2_w; ln.b = w.norm2_b; ln.M = n; ln.d = d; ln.eps = 1e-5f;
-    D3PM_TRY(run_layernorm(dt, ln, 0, s));
+    D3PM_TRY(run_layernorm(cx, dt, ln, 0, s));
   }
   LinearArgs g;   // timm Mlp: fc2(silu(fc1(x)))
   g.X = ws.x; g.ldx = d; g.W = e.fc1_w; g.bias = e.fc1_b; g.Y = ws.ff; g.ldy = e.mlp_hidden; g.M = n; g.N = e.mlp_hidden; g.K = d; g.act = ACT_SILU;
-  D3PM_TRY(run_linear(dt, g, 0, s));
+  D3PM_TRY(run_linear(cx, dt, g, 0, s));
   g = LinearArgs();
   g.X = ws.ff; g.ldx = e.mlp_hidden; g.W = e.fc2_w; g.bias = e.fc2_b; g.Y = out; g.ldy = d; g.M = n; g.N = d; g.K = e.mlp_hidden;
-  return run_linear(dt, g, 0, s);
+  return run_linear(cx, dt, g, 0, s);
 }
 
 static bool encoder_ok(const d3pm_encoder_weights& e, int d) {
@@ -594,8 +623,9 @@ static int sample_loop_impl(const d3pm_shape* sh, const d3pm_weights* w, int bat
   D3PM_REQUIRE(workspace_bytes >= ws.total, D3PM_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int rows = batch * sh->canvas;
+  const Ctx cx(sh->tuning);
   for (int t = t_start; t > t_stop; --t) {
-    g_prof.sample_now = (t % g_prof.stride) == 0;
+    if (cx.prof) cx.prof->sample_now = (t % cx.prof->stride) == 0;
     D3PM_TRY(denoiser_blocks(*sh, *w, batch, x, frame_mask, t, film, kv_text, kv_prompt, ws, sh->n_layers, flags, s, f8));
     SampleArgs a;
     a.logits = ws.logits; a.logits_dtype = sh->dtype; a.ldl = logits_ld(*sh); a.x_t = x; a.x_next = x;
@@ -605,19 +635,23 @@ static int sample_loop_impl(const d3pm_shape* sh, const d3pm_weights* w, int bat
     a.row0 = utt0 * static_cast<uint32_t>(sh->canvas); a.greedy = (flags & D3PM_FLAG_GREEDY) ? 1 : 0;
     a.pc = make_posterior_consts(sched, t);
     const double fin_flops = 2.0 * rows * sh->n_classes * sh->d_model;
+    (void)fin_flops;
+#ifdef D3PM_ABLATIONS
     if (fused_final_sample_applies(*sh, *w, ws, flags)) {
       // final projection + posterior + draw in one kernel: the logits stay on chip (d3pm_final_sample.hip)
-      ProfScope p(D3PM_K_SAMPLE, s, fin_flops,
+      ProfScope p(cx, D3PM_K_SAMPLE, s, fin_flops,
                   dtype_size(sh->dtype) * (static_cast<double>(rows) * sh->d_model + static_cast<double>(sh->n_classes) * sh->d_model) + 8.0 * rows);
       D3PM_TRY(final_sample(sh->dtype, ws.x, sh->d_model, w->final_w, w->final_b, sh->d_model, a, s));
-    } else {
+    } else
+#endif
+    {
       D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, logits_ld(*sh), flags, s));
-      ProfScope p(D3PM_K_SAMPLE, s, 0.0,
+      ProfScope p(cx, D3PM_K_SAMPLE, s, 0.0,
                   static_cast<double>(rows) * (sh->n_classes * dtype_size(sh->dtype) + 8.0));
       D3PM_TRY(posterior_sample(a, s));
     }
   }
-  g_prof.sample_now = false;
+  if (cx.prof) cx.prof->sample_now = false;
   return D3PM_OK;
 }
 
@@ -706,6 +740,7 @@ int d3pm_nar_level(const d3pm_nar_shape* sh, const d3pm_nar_weights* w, int batc
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int dt = sh->dtype, d = sh->d_model, n = batch * t_max, hd = d / sh->n_heads, stride = sh->n_resp_levels + 1;
   const size_t es = dtype_size(dt);
+  const Ctx cx(sh->tuning);
 
   NarEmbedArgs e;
   e.lens = lens; e.text = text; e.tt_max = tt_max; e.prom = prom; e.tp_max = tp_max; e.n_prom_levels = sh->n_prom_levels;
@@ -720,30 +755,30 @@ int d3pm_nar_level(const d3pm_nar_shape* sh, const d3pm_nar_weights* w, int batc
     D3PM_TRY(adaln(dt, ws.x, ws.h, at(b.attn_norm_emb, static_cast<size_t>(level) * 2 * d, es), ws.mask, n, d, s));
     LinearArgs g;
     g.X = ws.h; g.ldx = d; g.W = b.to_qkv_w; g.Y = ws.qkv; g.ldy = 3 * d; g.M = n; g.N = 3 * d; g.K = d;
-    D3PM_TRY(run_linear(dt, g, flags, s));
+    D3PM_TRY(run_linear(cx, dt, g, flags, s));
     AttnArgs a;
     a.Q = ws.qkv; a.ldq = 3 * d; a.K = at(ws.qkv, d, es); a.V = at(ws.qkv, 2 * d, es); a.ldkv = 3 * d; a.O = ws.att; a.ldo = d;
     a.B = batch; a.Tq = t_max; a.S = t_max; a.H = sh->n_heads; a.hd = hd; a.scale = 1.0f / std::sqrt(static_cast<float>(hd));
     a.key_len = ws.key_len;
-    D3PM_TRY(run_attention(dt, a, flags, s));
+    D3PM_TRY(run_attention(cx, dt, a, flags, s));
     g = LinearArgs();
     g.X = ws.att; g.ldx = d; g.W = b.to_out_w; g.bias = b.to_out_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
     g.row_mask = ws.mask; g.mask_period = n; g.M = n; g.N = d; g.K = d;
-    D3PM_TRY(run_linear(dt, g, flags, s));
+    D3PM_TRY(run_linear(cx, dt, g, flags, s));
     // x = (x + ffn(AdaLN(x) * m)) * m
     D3PM_TRY(adaln(dt, ws.x, ws.h, at(b.ffn_norm_emb, static_cast<size_t>(level) * 2 * d, es), ws.mask, n, d, s));
     g = LinearArgs();
     g.X = ws.h; g.ldx = d; g.W = b.ffn0_w; g.bias = b.ffn0_b; g.Y = ws.ffn; g.ldy = 4 * d; g.M = n; g.N = 4 * d; g.K = d; g.act = ACT_GELU;
-    D3PM_TRY(run_linear(dt, g, flags, s));
+    D3PM_TRY(run_linear(cx, dt, g, flags, s));
     g = LinearArgs();
     g.X = ws.ffn; g.ldx = 4 * d; g.W = b.ffn3_w; g.bias = b.ffn3_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
     g.row_mask = ws.mask; g.mask_period = n; g.M = n; g.N = d; g.K = 4 * d;
-    D3PM_TRY(run_linear(dt, g, flags, s));
+    D3PM_TRY(run_linear(cx, dt, g, flags, s));
   }
   LinearArgs g;
   g.X = ws.x; g.ldx = d; g.W = w->classifier_w; g.bias = w->classifier_b; g.Y = ws.logits; g.ldy = sh->n_tokens; g.M = n;
   g.N = sh->n_tokens; g.K = d;
-  D3PM_TRY(run_linear(dt, g, flags, s));
+  D3PM_TRY(run_linear(cx, dt, g, flags, s));
   if (logits_out)
     D3PM_CHECK_HIP(hipMemcpyAsync(logits_out, ws.logits, static_cast<size_t>(n) * sh->n_tokens * es, hipMemcpyDeviceToDevice, s));
   return nar_sample(dt, ws.logits, sh->n_tokens, lens, resp, tr_max, stride, t_max, sh->n_tokens, level, temperature, seed, utt0,
@@ -752,9 +787,11 @@ int d3pm_nar_level(const d3pm_nar_shape* sh, const d3pm_nar_weights* w, int batc
 
 int d3pm_op_linear(int dtype, int family, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy,
                    const void* R1, const void* R2, int ldr, const uint8_t* row_mask, int mask_period, int M, int N, int K,
-                   int act, void* stream) {
+                   int act, const d3pm_tuning* tuning, void* stream) {
   D3PM_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0, D3PM_E_ARG, "d3pm_op_linear: bad arguments");
+  const Ctx cx(tuning);
   LinearArgs g;
+  g.tune = tuning;
   g.X = X; g.ldx = ldx; g.W = W; g.bias = bias; g.Y = Y; g.ldy = ldy; g.R1 = R1; g.R2 = R2; g.ldr = ldr;
   g.row_mask = row_mask; g.mask_period = mask_period > 0 ? mask_period : 1; g.M = M; g.N = N; g.K = K; g.act = act;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -763,7 +800,7 @@ int d3pm_op_linear(int dtype, int family, const void* X, int ldx, const void* W,
     D3PM_REQUIRE(mfma_linear_supported(dtype, g), D3PM_E_SHAPE, "d3pm_op_linear: shape not supported by the MFMA kernel");
     return mfma_linear(dtype, g, s);
   }
-  return run_linear(dtype, g, 0, s);
+  return run_linear(cx, dtype, g, 0, s);
 }
 
 int d3pm_op_linear_fp8(int out_dtype, const void* X8, int ldx, const float* sx, const void* W8, const float* sw, const void* bias,
@@ -783,9 +820,11 @@ int d3pm_op_layernorm_fp8(int dtype, const void* X, void* Y8, float* sx, const v
 }
 
 int d3pm_op_attention(int dtype, int family, const void* Q, int ldq, const void* K, const void* V, int ldkv, void* O,
-                      int ldo, int B, int Tq, int S, int H, int hd, float scale, void* stream) {
+                      int ldo, int B, int Tq, int S, int H, int hd, float scale, const d3pm_tuning* tuning, void* stream) {
   D3PM_REQUIRE(Q && K && V && O && B > 0 && Tq > 0 && S > 0 && H > 0 && hd > 0, D3PM_E_ARG, "d3pm_op_attention: bad arguments");
+  const Ctx cx(tuning);
   AttnArgs a;
+  a.tune = tuning;
   a.Q = Q; a.ldq = ldq; a.K = K; a.V = V; a.ldkv = ldkv; a.O = O; a.ldo = ldo; a.B = B; a.Tq = Tq; a.S = S; a.H = H;
   a.hd = hd; a.scale = scale;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -794,7 +833,7 @@ int d3pm_op_attention(int dtype, int family, const void* Q, int ldq, const void*
     D3PM_REQUIRE(mfma_attention_supported(dtype, a), D3PM_E_SHAPE, "d3pm_op_attention: shape not supported by the MFMA kernel");
     return mfma_attention(dtype, a, s);
   }
-  return run_attention(dtype, a, 0, s);
+  return run_attention(cx, dtype, a, 0, s);
 }
 
 int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const void* b, const void* film, int M, int d,
@@ -802,9 +841,11 @@ int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const vo
   D3PM_REQUIRE(X && Y && w && b && M > 0 && d > 0, D3PM_E_ARG, "d3pm_op_layernorm: bad arguments");
   LayerNormArgs ln;
   ln.X = X; ln.Y = Y; ln.w = w; ln.b = b; ln.film = film; ln.M = M; ln.d = d; ln.eps = eps;
-  return run_layernorm(dtype, ln, 0, static_cast<hipStream_t>(stream));
+  const Ctx cx(nullptr);
+  return run_layernorm(cx, dtype, ln, 0, static_cast<hipStream_t>(stream));
 }
 
+#ifdef D3PM_ABLATIONS
 int d3pm_op_linear_lnpro(int dtype, const void* X, const void* W, const void* bias, void* Y, int M, int N, int act, const void* ln_w,
                          const void* ln_b, const void* ln2_w, const void* ln2_b, const void* film, float eps, void* stream) {
   D3PM_REQUIRE(X && W && Y && ln_w && ln_b && M > 0 && N > 0, D3PM_E_ARG, "d3pm_op_linear_lnpro: bad arguments");
@@ -817,6 +858,8 @@ int d3pm_op_linear_lnpro(int dtype, const void* X, const void* W, const void* bi
                "LayerNorm, M = 2 x a multiple of 64 rows and no FiLM");
   return ln_prologue_linear(dtype, g, lp, static_cast<hipStream_t>(stream));
 }
+
+#endif
 
 int d3pm_op_linear_rowpanel(int dtype, const void* X, const void* X2, int ldx, const void* W, const void* bias, void* Y, const void* R1,
                             const uint8_t* row_mask, int mask_period, int M, int K, const void* ln_w, const void* ln_b, void* ln_y,
@@ -833,6 +876,7 @@ int d3pm_op_linear_rowpanel(int dtype, const void* X, const void* X2, int ldx, c
   return row_panel_linear(dtype, g, f, static_cast<hipStream_t>(stream));
 }
 
+#ifdef D3PM_ABLATIONS
 int d3pm_op_final_sample(const d3pm_shape* sh, const d3pm_weights* w, int batch, const void* hidden, const int32_t* x_t,
                          int32_t* x_next, int t, const d3pm_schedule* sched, uint64_t seed, uint32_t utt0, uint32_t flags,
                          void* stream) {
@@ -849,6 +893,8 @@ int d3pm_op_final_sample(const d3pm_shape* sh, const d3pm_weights* w, int batch,
   return final_sample(sh->dtype, hidden, sh->d_model, w->final_w, w->final_b, sh->d_model, a, static_cast<hipStream_t>(stream));
 }
 
+#endif
+
 int d3pm_op_cond_embed(int dtype, int which, const int32_t* tokens, int n_levels, const void* tables, const void* pe, void* y, int rows,
                        int s_prompt, int d, int n_classes, void* stream) {
   D3PM_REQUIRE(tokens && tables && pe && y && rows > 0 && d > 0 && n_classes > 0, D3PM_E_ARG, "d3pm_op_cond_embed: bad arguments");
@@ -858,20 +904,24 @@ int d3pm_op_cond_embed(int dtype, int which, const int32_t* tokens, int n_levels
   return cond_embed_prompt(dtype, tokens, n_levels, tables, pe, y, rows, s_prompt, d, n_classes, s);
 }
 
-int d3pm_set_tuning(int knob, int value) {
-  if (knob == D3PM_TUNE_GEMM_VARIANT && (value == 0 || (value >= 2 && value <= 9))) { set_gemm_variant(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_ATTN_QUERY_GROUPS && ((value >= 0 && value <= 3) || (value >= 100 && value <= 164) || value == 228 || value == 201 || value == 202)) { set_attn_qg(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_ATTN_PAIR_SEQUENTIAL && value >= 0 && value <= 2) { set_attn_pair_sequential(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_GEMM_BIG_MODE && (value == 0 || value == 1 || value == 3 || value == 5 || value == 9 || value == 17 || value == 32 || value == 81 || value == 209 || value == 145 || value == 257 || value == 465 || value == 513 || value == 1025 || value == 2049 || value == 4129 || value == 33)) { set_big_gemm_mode(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_GELU_TABLE && (value == 0 || value == 1)) { set_gelu_table(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_ATTN_CROSS_RESIDENT && value >= 0 && value <= 3) { set_attn_cross_resident(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_FUSED_FINAL_SAMPLE && (value == 0 || value == 1)) { g_fused_final_sample = value; return D3PM_OK; }
-  if (knob == D3PM_TUNE_WORKSPACE_ALIAS && (value == 0 || value == 1)) { g_ws_alias = value; return D3PM_OK; }
-  if (knob == D3PM_TUNE_LAT_TILE && value >= 0 && value <= 3) { set_lat_tile(value); return D3PM_OK; }
-  if (knob == D3PM_TUNE_LN_PROLOGUE && (value == 0 || value == 1)) { g_ln_prologue = value; return D3PM_OK; }
-  if (knob == D3PM_TUNE_ROW_PANEL && value >= 0 && value <= 7) { g_row_panel = value; return D3PM_OK; }
-  if (knob == D3PM_TUNE_GEMM_PERSIST_SLOTS && value >= 8 && value <= 4096 && value % 8 == 0) { set_gemm_persist_slots(value); return D3PM_OK; }
-  set_error("d3pm_set_tuning: unknown knob %d / value %d", knob, value);
+void d3pm_tuning_default(d3pm_tuning* t) {
+  if (t) *t = tune_of(nullptr);
+}
+
+#ifdef D3PM_ABLATIONS
+int d3pm_ab_set(int knob, int value) {
+  AbKnobs& k = ab_knobs();
+  static const int big_modes[] = {0, 1, 3, 5, 9, 17, 32, 33, 81, 145, 209, 257, 465, 513, 1025, 2049, 4129};
+  if (knob == D3PM_AB_GEMM_BIG_MODE) {
+    for (int m : big_modes)
+      if (m == value) { k.big_mode = value; return D3PM_OK; }
+  }
+  if (knob == D3PM_AB_ATTN_ARM && (value == 0 || value == 3 || (value >= 100 && value <= 164) || value == 228 || value == 201 || value == 202)) { k.attn_arm = value; return D3PM_OK; }
+  if (knob == D3PM_AB_GEMM_RING && (value == 0 || value == 1)) { k.ring = value; return D3PM_OK; }
+  if (knob == D3PM_AB_GELU_TABLE && (value == 0 || value == 1)) { k.gelu_table = value; return D3PM_OK; }
+  if (knob == D3PM_AB_LN_PROLOGUE && (value == 0 || value == 1)) { k.ln_prologue = value; return D3PM_OK; }
+  if (knob == D3PM_AB_FUSED_FINAL_SAMPLE && (value == 0 || value == 1)) { k.fused_final_sample = value; return D3PM_OK; }
+  set_error("d3pm_ab_set: unknown knob %d / value %d", knob, value);
   return D3PM_E_ARG;
 }
 
@@ -879,62 +929,69 @@ int d3pm_debug_gemm_clock(unsigned long long* clocks_and_ticks) {
   D3PM_REQUIRE(clocks_and_ticks, D3PM_E_ARG, "d3pm_debug_gemm_clock: null pointer");
   return read_big_gemm_stamp(clocks_and_ticks);
 }
+#endif
 
-int d3pm_prof_enable(int kclass, int max_events) {
-  D3PM_REQUIRE(kclass >= 0 && kclass <= D3PM_K_COUNT && max_events > 0, D3PM_E_ARG, "d3pm_prof_enable: bad arguments");
-  d3pm_prof_disable();
-  g_prof.ev.resize(static_cast<size_t>(max_events) * 2);
-  g_prof.cls.assign(static_cast<size_t>(max_events), -1);
-  for (auto& e : g_prof.ev) D3PM_CHECK_HIP(hipEventCreate(&e));
-  g_prof.kclass = kclass;
-  g_prof.used = 0;
-  for (int c = 0; c < D3PM_K_COUNT; ++c) g_prof.flops[c] = g_prof.bytes[c] = 0;
+int d3pm_prof_create(int kclass, int max_events, d3pm_prof** out) {
+  D3PM_REQUIRE(out && kclass >= 0 && kclass <= D3PM_K_COUNT && max_events > 0, D3PM_E_ARG, "d3pm_prof_create: bad arguments");
+  d3pm_prof* p = new (std::nothrow) d3pm_prof();
+  D3PM_REQUIRE(p, D3PM_E_ARG, "d3pm_prof_create: out of host memory");
+  p->ev.resize(static_cast<size_t>(max_events) * 2);
+  p->cls.assign(static_cast<size_t>(max_events), -1);
+  for (auto& e : p->ev) {
+    if (hipEventCreate(&e) != hipSuccess) {
+      set_error("d3pm_prof_create: hipEventCreate failed");
+      p->ev.clear();
+      delete p;
+      return D3PM_E_HIP;
+    }
+  }
+  p->kclass = kclass;
+  *out = p;
   return D3PM_OK;
 }
 
-int d3pm_prof_read_class(int kclass, int* launches, double* total_ms, double* flops, double* bytes) {
-  D3PM_REQUIRE(kclass >= 0 && kclass < D3PM_K_COUNT, D3PM_E_ARG, "d3pm_prof_read_class: bad class");
+int d3pm_prof_read_class(d3pm_prof* p, int kclass, int* launches, double* total_ms, double* flops, double* bytes) {
+  D3PM_REQUIRE(p && kclass >= 0 && kclass < D3PM_K_COUNT, D3PM_E_ARG, "d3pm_prof_read_class: bad arguments");
   double ms = 0;
   int n = 0;
-  for (int i = 0; i + 1 < g_prof.used; i += 2) {
-    if (g_prof.cls[i / 2] != kclass) continue;
-    D3PM_CHECK_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
+  for (int i = 0; i + 1 < p->used; i += 2) {
+    if (p->cls[i / 2] != kclass) continue;
+    D3PM_CHECK_HIP(hipEventSynchronize(p->ev[i + 1]));
     float m = 0;
-    D3PM_CHECK_HIP(hipEventElapsedTime(&m, g_prof.ev[i], g_prof.ev[i + 1]));
+    D3PM_CHECK_HIP(hipEventElapsedTime(&m, p->ev[i], p->ev[i + 1]));
     ms += m;
     ++n;
   }
   if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
-  if (flops) *flops = g_prof.flops[kclass];
-  if (bytes) *bytes = g_prof.bytes[kclass];
+  if (flops) *flops = p->flops[kclass];
+  if (bytes) *bytes = p->bytes[kclass];
   return D3PM_OK;
 }
 
-int d3pm_prof_read(int* launches, double* total_ms, double* flops, double* bytes) {
+int d3pm_prof_read(d3pm_prof* p, int* launches, double* total_ms, double* flops, double* bytes) {
+  D3PM_REQUIRE(p, D3PM_E_ARG, "d3pm_prof_read: null handle");
   int n = 0;
   double ms = 0, fl = 0, by = 0;
   for (int c = 0; c < D3PM_K_COUNT; ++c) {
     int nc = 0;
     double mc = 0, fc = 0, bc = 0;
-    D3PM_TRY(d3pm_prof_read_class(c, &nc, &mc, &fc, &bc));
+    D3PM_TRY(d3pm_prof_read_class(p, c, &nc, &mc, &fc, &bc));
     n += nc; ms += mc; fl += fc; by += bc;
   }
   if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
   if (flops) *flops = fl;
   if (bytes) *bytes = by;
-  g_prof.used = 0;
-  for (int c = 0; c < D3PM_K_COUNT; ++c) g_prof.flops[c] = g_prof.bytes[c] = 0;
+  p->used = 0;
+  for (int c = 0; c < D3PM_K_COUNT; ++c) p->flops[c] = p->bytes[c] = 0;
   return D3PM_OK;
 }
 
-int d3pm_prof_disable(void) {
-  for (auto& e : g_prof.ev) (void)hipEventDestroy(e);
-  g_prof.ev.clear();
-  g_prof.cls.clear();
-  g_prof.kclass = -1;
-  g_prof.used = 0;
+int d3pm_prof_destroy(d3pm_prof* p) {
+  if (!p) return D3PM_OK;
+  for (auto& e : p->ev) (void)hipEventDestroy(e);
+  delete p;
   return D3PM_OK;
 }
 

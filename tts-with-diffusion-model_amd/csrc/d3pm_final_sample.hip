@@ -21,6 +21,8 @@
 //            bit-identical to the two-launch path (tests/test_gpu_kernels.py).
 // Two workgroups share a CU (66.5 KB of LDS each), so one's sampling arithmetic (VALU, transcendentals, Philox) runs
 // under the other's MFMAs.
+// Compiled into libd3pm_hip_ab.so only (-DD3PM_ABLATIONS; include/d3pm_hip_ab.h): built, measured, not shipped.
+#ifdef D3PM_ABLATIONS
 #include "d3pm_kernels.h"
 #include "d3pm_mfma_tile.h"
 #include "d3pm_sample_row.h"
@@ -148,3 +150,5 @@ int final_sample(int dtype, const void* X, int ldx, const void* W, const void* b
 }
 
 }  // namespace d3pm
+
+#endif  // D3PM_ABLATIONS

@@ -10,6 +10,21 @@ namespace d3pm {
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SILU = 3 };
 
+// Schedule choices travel with the arguments of a launch (include/d3pm_hip.h: d3pm_tuning); nullptr = the defaults.
+// The library has no mutable global state: the defaults are a constant.
+inline const d3pm_tuning& tune_of(const d3pm_tuning* t) {
+  static const d3pm_tuning kDefault = {/*gemm_variant*/ 0, /*gemm_persist_slots*/ 1024, /*lat_tile*/ 0, /*attn_query_groups*/ 0,
+                                       /*attn_pair_sequential*/ 1, /*attn_cross_resident*/ 1, /*row_panel*/ 3, /*workspace_alias*/ 1,
+                                       /*prof*/ nullptr};
+  return t ? *t : kDefault;
+}
+
+#ifdef D3PM_ABLATIONS
+// libd3pm_hip_ab.so only (include/d3pm_hip_ab.h): process-wide knobs of the experiments that did not ship
+struct AbKnobs { int big_mode = 1, attn_arm = 0, ring = 0, gelu_table = 0, ln_prologue = 0, fused_final_sample = 0; };
+AbKnobs& ab_knobs();
+#endif
+
 // Y[M][N] = epilogue(X[M][K] . W[N][K]^T + bias)      (torch.nn.functional.linear layout)
 // epilogue, with rn() = round to the storage dtype exactly where the eager reference rounds:
 //   v = rn(acc + bias); if act: v = rn(act(v))   (exact-erf GELU, ReLU or SiLU);
@@ -24,6 +39,7 @@ struct LinearArgs {
   const uint8_t* row_mask = nullptr; int mask_period = 1;
   int M = 0, N = 0, K = 0;
   int act = ACT_NONE;
+  const d3pm_tuning* tune = nullptr;
 };
 
 // O[b][i][h*hd+c] = sum_j P[i][j] V[b][j][h*hd+c],  P = rn(softmax(rn(rn(q*scale) . k)))
@@ -40,6 +56,7 @@ struct AttnArgs {
   // optional second, independent problem with the same B / Tq / H / hd launched in the same grid
   // (the text and prompt cross-attentions of one DiT block): its own Q, K/V (S2 keys) and output
   const void* Q2 = nullptr; const void* K2 = nullptr; const void* V2 = nullptr; void* O2 = nullptr; int S2 = 0;
+  const d3pm_tuning* tune = nullptr;
 };
 
 // Y = LN(X) * w + b (eps), optionally FiLM: Y = rn(rn(LN * rn(1 + film[c])) + film[d + c])
@@ -120,9 +137,11 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a);
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s);
 bool mfma_attention_supported(int dtype, const AttnArgs& a);
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s);
+#ifdef D3PM_ABLATIONS
 bool panel64_ln_supported(int dtype, const LinearArgs& a, const LnPrologue& ln);
 bool ln_prologue_linear_applies(int dtype, const LinearArgs& a, const LnPrologue& ln);   // would mfma_linear pick the latency GEMM?
 int ln_prologue_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, hipStream_t s);
+#endif
 bool row_panel_supported(int dtype, const LinearArgs& a, const RowPanelFuse& f);
 int row_panel_linear(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s);
 bool fast_layernorm_supported(int dtype, const LayerNormArgs& a);

@@ -75,7 +75,7 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2v){a, b}, pair));
 }
 
-// ABL: timing-only ablation builds (WRONG results; tests/ab_attn.py): 1 no v_exp, 2 no maximum / rescale logic, 4 no K/V
+// ABL != 0 is instantiated in the A/B library only (-DD3PM_ABLATIONS): timing-only ablation builds (results wrong by construction; tests/ab_attn.py): 1 no v_exp, 2 no maximum / rescale logic, 4 no K/V
 // staging after the first tile, 8 no barriers, 16 no P.V product, 32 no Q.K product
 // fragment reads whose completion is waited for by hand (ABL bit 6: every K and V fragment of a tile issued at the top of
 // the tile, counted lgkmcnt before each consumer) -- hipcc sinks a plain LDS load to the instruction before its first use
@@ -630,21 +630,23 @@ bool mfma_attention_supported(int dtype, const AttnArgs& a) {
   return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 8);
 }
 
-// 0 = auto: two 16-query groups per wave (each K / V fragment read from LDS feeds two MFMAs; 63.8 vs 65.8 us on the
-// 768 x 768 x 256-head self-attention, 27.7 vs 30.1 us on the 225-key prompt attention) once that still leaves >= 4
-// workgroups per CU, one group otherwise (a single utterance is 48 workgroups of two groups: latency regime)
-static int g_attn_qg = 0;
-static int g_attn_pair_seq = 1;      // 0 never, 1 auto (when the paired grid still has >= 2 workgroups per CU), 2 always
-void set_attn_qg(int v) { g_attn_qg = v; }
-void set_attn_pair_sequential(int v) { g_attn_pair_seq = v; }
-
-// cross-attention pair with every K / V tile resident in LDS (attn_cross_hd64): 0 never, 1 auto, 2 always.  Auto = when its
-// grid (256 queries per workgroup) has at least one workgroup per CU: at one utterance it is 24 workgroups of eight waves and
-// the tile-by-tile kernel's 192 small ones finish sooner (p50 latency 46.7 -> 42.2 ms, profiles/round2_d_latency_ab.txt)
-static int g_attn_cross_resident = 1;
-void set_attn_cross_resident(int v) { g_attn_cross_resident = v; }
+// d3pm_tuning.attn_query_groups: 0 = auto: two 16-query groups per wave (each K / V fragment read from LDS feeds two MFMAs;
+// 63.8 vs 65.8 us on the 768 x 768 x 256-head self-attention, 27.7 vs 30.1 us on the 225-key prompt attention) once that still
+// leaves >= 4 workgroups per CU, one group otherwise (a single utterance is 48 workgroups of two groups: latency regime).
+// attn_pair_sequential: 0 never, 1 auto (when the paired grid still has >= 2 workgroups per CU), 2 always.
+// attn_cross_resident: cross-attention pair with every K / V tile resident in LDS (attn_cross_hd64): 0 never, 1 auto, 2 always.
+// Auto = when its grid (256 queries per workgroup) has at least one workgroup per CU: at one utterance it is 24 workgroups of
+// eight waves and the tile-by-tile kernel's 192 small ones finish sooner (p50 latency 46.7 -> 42.2 ms,
+// profiles/round2_d_latency_ab.txt)
 
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
+  const d3pm_tuning& tn = tune_of(a.tune);
+  const int g_attn_cross_resident = tn.attn_cross_resident, g_attn_pair_seq = tn.attn_pair_sequential;
+#ifdef D3PM_ABLATIONS
+  const int g_attn_qg = ab_knobs().attn_arm ? ab_knobs().attn_arm : tn.attn_query_groups;      // arms >= 3: include/d3pm_hip_ab.h
+#else
+  const int g_attn_qg = (tn.attn_query_groups == 1 || tn.attn_query_groups == 2) ? tn.attn_query_groups : 0;
+#endif
   const long long cross_wgs = static_cast<long long>((a.Tq + 255) / 256) * a.H * a.B;
   if ((g_attn_cross_resident >= 2 || (g_attn_cross_resident == 1 && cross_wgs >= 256)) && a.Q2 != nullptr && a.key_len == nullptr &&
       a.S <= BKV && a.S2 <= 4 * BKV) {
@@ -689,6 +691,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     if (seq) { if (qg == 1) D3PM_ATTN(T, 1, true); else D3PM_ATTN(T, 2, true); }           \
     else { if (qg == 1) D3PM_ATTN(T, 1, false); else D3PM_ATTN(T, 2, false); }             \
   } while (0)
+#ifdef D3PM_ABLATIONS
   if (g_attn_qg == 3 && dtype == D3PM_BF16 && !a.Q2) {        // three query groups per wave (A/B: fewer LDS reads per MFMA, two waves per SIMD)
     D3PM_ATTN(bf16, 3, false);
   } else if (g_attn_qg >= 200 && dtype == D3PM_BF16 && !a.Q2) {      // occupancy probe: the shipped QG = 2 kernel with idle dynamic LDS
@@ -710,7 +713,9 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
       default: D3PM_ATTN(bf16, 2, false);
     }
 #undef D3PM_ABL
-  } else if (dtype == D3PM_F16) D3PM_ATTN_QG(f16); else D3PM_ATTN_QG(bf16);
+  } else
+#endif
+  if (dtype == D3PM_F16) D3PM_ATTN_QG(f16); else D3PM_ATTN_QG(bf16);
 #undef D3PM_ATTN_QG
 #undef D3PM_ATTN
   D3PM_LAUNCH_CHECK();

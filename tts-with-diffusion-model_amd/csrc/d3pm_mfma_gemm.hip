@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128_persist(const T* __restr
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+#ifdef D3PM_ABLATIONS
 __device__ uint16_t g_gelu_bf16[GELU_TAB_ENTRIES];
 __global__ void fill_gelu_table() {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -338,9 +339,11 @@ __global__ void fill_gelu_table() {
   const float v = __uint_as_float(bits << 16);
   g_gelu_bf16[i] = static_cast<uint16_t>(__float_as_uint(rn<bf16>(gelu_erf(v))) >> 16);
 }
+#endif
 
 }  // namespace
 
+#ifdef D3PM_ABLATIONS
 // Device address of the bf16 GELU table (d3pm_mfma_tile.h), filled on first use on `s` (a static of the library: no
 // allocation; the fill kernel is idempotent, so a capture that happens to contain it replays harmlessly).
 const uint16_t* gelu_table_device(hipStream_t s) {
@@ -354,6 +357,7 @@ const uint16_t* gelu_table_device(hipStream_t s) {
   }
   return ptr;
 }
+#endif
 
 bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
@@ -371,36 +375,38 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
-// 0 auto, 2 throughput (128 x 128 persistent over whole tiles), 3 the round-1 latency schedule (128 x 128, two stages), 4 the
-// latency schedule (64 x 64 tiles, whole-K panels), 5 throughput with one 128 x 128 tile per workgroup,
-// 6 / 7 / 8 big tiles (192 x 256 / 96 x 512 / 192 x 128, d3pm_mfma_gemm_big.hip) wherever they apply, else as auto without big tiles
-static int g_gemm_variant = 0;
-static int g_persist_slots = 1024;   // resident workgroups of the persistent schedule: 4 per CU x 256 CUs
-void set_gemm_variant(int v) { g_gemm_variant = v; }
-void set_gemm_persist_slots(int v) { g_persist_slots = v; }
-
+// d3pm_tuning.gemm_variant: 0 auto, 2 throughput (128 x 128 persistent over whole tiles), 3 the round-1 latency schedule
+// (128 x 128, two stages), 4 the latency schedule (64 x 64 tiles, whole-K panels), 5 throughput with one 128 x 128 tile per
+// workgroup, 6 / 7 / 8 big tiles (192 x 256 / 96 x 512 / 192 x 128, d3pm_mfma_gemm_big.hip) wherever they apply, else as auto
+// without big tiles.  gemm_persist_slots: resident workgroups of the persistent schedule (1024 = 4 per CU x 256 CUs).
 bool panel64_linear_supported(int dtype, const LinearArgs& a);
-bool panel64_ln_supported(int dtype, const LinearArgs& a, const LnPrologue& ln);
 int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s, const LnPrologue* ln = nullptr);
 int big_linear_tile(int dtype, const LinearArgs& a, int want);
 int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s);
+
+#ifdef D3PM_ABLATIONS
 bool ring_linear_supported(int dtype, const LinearArgs& a);
 int ring_linear(int dtype, const LinearArgs& a, hipStream_t s);
-
 // The LayerNorm-prologue form exists for the latency schedule only: true where mfma_linear would pick that schedule anyway
 bool ln_prologue_linear_applies(int dtype, const LinearArgs& a, const LnPrologue& ln) {
-  const bool autosel = g_gemm_variant == 0;
-  if (!(g_gemm_variant == 4 || (autosel && a.M <= 1536))) return false;
+  const int variant = tune_of(a.tune).gemm_variant;
+  const bool autosel = variant == 0;
+  if (!(variant == 4 || (autosel && a.M <= 1536))) return false;
   if (autosel && big_linear_tile(dtype, a, 0)) return false;
   return panel64_ln_supported(dtype, a, ln);
 }
 int ln_prologue_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, hipStream_t s) { return panel64_linear(dtype, a, s, &ln); }
+#endif
 
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   // All schedules accumulate in the same order, so the choice never changes a bit of the result.
   const bool ffn_act = a.act == ACT_RELU || a.act == ACT_SILU;
-  if (g_gemm_variant == 9 && ring_linear_supported(dtype, a)) return ring_linear(dtype, a, s);   // experimental ring schedule
-  const bool autosel = g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 9);
+  const d3pm_tuning& tn = tune_of(a.tune);
+  const int g_gemm_variant = tn.gemm_variant, g_persist_slots = tn.gemm_persist_slots >= 8 ? (tn.gemm_persist_slots & ~7) : 1024;
+#ifdef D3PM_ABLATIONS
+  if (ab_knobs().ring && ring_linear_supported(dtype, a)) return ring_linear(dtype, a, s);   // experimental ring schedule
+#endif
+  const bool autosel = g_gemm_variant == 0 || (g_gemm_variant >= 6 && g_gemm_variant <= 8);
   if (autosel) {
     const int id = big_linear_tile(dtype, a, g_gemm_variant == 6 ? 2 : g_gemm_variant == 7 ? 1 : g_gemm_variant == 8 ? 3 : 0);
     if (id) return big_linear(dtype, a, id, s);

@@ -53,7 +53,8 @@ __device__ __forceinline__ void glds16_m0(const void* sbase, uint32_t voff, uint
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-// MODE: bit 0 = hand-scheduled fragment reads (asm, counted lgkmcnt); bit 3 (8) = deferred stores: a tile's 12 output stores
+// MODE: 1 is the shipped schedule; every other value is instantiated in the A/B library only (-DD3PM_ABLATIONS, include/d3pm_hip_ab.h).
+// bit 0 = hand-scheduled fragment reads (asm, counted lgkmcnt); bit 3 (8) = deferred stores: a tile's 12 output stores
 // per wave are issued a few per k-step inside the NEXT tile's main loop (all CUs finish their tiles together, so stores
 // issued in the epilogue arrive as one chip-wide burst that the HBM write path drains at ~5.5 TB/s while every MFMA pipe
 // idles: 4.5 us per 25 MB round; needs K >= 512); the other bits are timing-only ablations (WRONG
@@ -492,13 +493,15 @@ static void big_geometry(int id, int& tm, int& tn, int& waves) {
   waves = id == 3 ? 4 : 8;
 }
 
+#ifdef D3PM_ABLATIONS
 const uint16_t* gelu_table_device(hipStream_t s);
-// D3PM_TUNE_GELU_TABLE: bf16 GELU epilogues read an LDS table (d3pm_mfma_tile.h).  Off: measured SLOWER on MI355X -- fc1 + GELU at
-// M = 24576 with 192 x 256 tiles 86.4 us with the table vs 72.6 us with the polynomial (67.9 us for the shipped 192 x 128
+// D3PM_AB_GELU_TABLE: bf16 GELU epilogues read an LDS table (d3pm_mfma_tile.h).  Not shipped: measured SLOWER on MI355X -- fc1 +
+// GELU at M = 24576 with 192 x 256 tiles 86.4 us with the table vs 72.6 us with the polynomial (67.9 us for the shipped 192 x 128
 // geometry); 64 random 2-byte LDS reads per instruction cost more than the 17 vector instructions they replace
-static int g_gelu_table = 0;
-void set_gelu_table(int v) { g_gelu_table = v; }
-int gelu_table_enabled() { return g_gelu_table; }
+int gelu_table_enabled() { return ab_knobs().gelu_table; }
+#else
+static int gelu_table_enabled() { return 0; }
+#endif
 
 // 0 = not applicable, else the geometry id.  `want` (tuning knob): 0 auto, 1 / 2 / 3 forced.
 int big_linear_tile(int dtype, const LinearArgs& a, int want) {
@@ -524,27 +527,31 @@ int big_linear_tile(int dtype, const LinearArgs& a, int want) {
   if (want >= 1 && want <= 3) return fits(want, true) ? want : 0;
   // measured at the bench shapes (tests/ab_gemm.py, profiles/round2_*): 192 x 256 wins everywhere except under the GELU
   // epilogue, whose VALU work only overlaps with MFMAs when a second workgroup shares the CU (192 x 128, two per CU)
-  if (gelu && !(dtype == D3PM_BF16 && g_gelu_table) && fits(3, false)) return 3;   // bf16: table lookup, cheap enough for one WG per CU
+  if (gelu && !(dtype == D3PM_BF16 && gelu_table_enabled()) && fits(3, false)) return 3;   // bf16: table lookup, cheap enough for one WG per CU
   if (fits(2, false)) return 2;
   if (fits(3, false)) return 3;
   return fits(1, false) ? 1 : 0;
 }
 
-static int g_big_mode = 1;      // kernel MODE template argument (tuning / ablation builds); 1 = shipped schedule (hand-placed reads)
-void set_big_gemm_mode(int v) { g_big_mode = v; }
-int big_gemm_mode() { return g_big_mode; }
+// kernel MODE template argument: 1 = the shipped schedule (hand-placed reads); every other value is an experiment that
+// exists in libd3pm_hip_ab.so only (include/d3pm_hip_ab.h, D3PM_AB_GEMM_BIG_MODE)
+#ifdef D3PM_ABLATIONS
+int big_gemm_mode() { return ab_knobs().big_mode; }
 int read_big_gemm_stamp(unsigned long long* out) {
   D3PM_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_stamp), 2 * sizeof(unsigned long long)));
   return D3PM_OK;
 }
+#endif
 
 template <typename U, int E, int WM, int WN, int MD>
 static int big_launch(const LinearArgs& a, int n_tiles, int tiles_total, dim3 grid, size_t lds, hipStream_t s) {
   const uint16_t* tab = nullptr;
-  if ((E & EPI_GELU) && std::is_same<U, bf16>::value && WM * WN == 8 && lds + GELU_TAB_BYTES <= 160 * 1024 && g_gelu_table) {
+#ifdef D3PM_ABLATIONS
+  if ((E & EPI_GELU) && std::is_same<U, bf16>::value && WM * WN == 8 && lds + GELU_TAB_BYTES <= 160 * 1024 && gelu_table_enabled()) {
     tab = gelu_table_device(s);
     if (tab) lds += GELU_TAB_BYTES;
   }
+#endif
   static bool attr_set = false;
   if (!attr_set) {
     D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_big<U, E, WM, WN, MD>),
@@ -561,7 +568,12 @@ static int big_launch(const LinearArgs& a, int n_tiles, int tiles_total, dim3 gr
 
 template <typename U, int E>
 static int big_launch_geometry(int id, const LinearArgs& a, int n_tiles, int tiles_total, dim3 grid, size_t lds, hipStream_t s) {
-  const int md = g_big_mode;
+#ifndef D3PM_ABLATIONS
+  if (id == 1) return big_launch<U, E, 1, 8, 1>(a, n_tiles, tiles_total, grid, lds, s);
+  if (id == 2) return big_launch<U, E, 2, 4, 1>(a, n_tiles, tiles_total, grid, lds, s);
+  return big_launch<U, E, 2, 2, 1>(a, n_tiles, tiles_total, grid, lds, s);
+#else
+  const int md = big_gemm_mode();
   if (E == 0 && id == 3 && md >= 16) {
     switch (md) {
       case 17: return big_launch<U, 0, 2, 2, 17>(a, n_tiles, tiles_total, grid, lds, s);
@@ -602,6 +614,7 @@ static int big_launch_geometry(int id, const LinearArgs& a, int n_tiles, int til
   if (id == 1) return drip ? big_launch<U, E, 1, 8, 9>(a, n_tiles, tiles_total, grid, lds, s) : hand ? big_launch<U, E, 1, 8, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 1, 8, 0>(a, n_tiles, tiles_total, grid, lds, s);
   if (id == 2) return drip ? big_launch<U, E, 2, 4, 9>(a, n_tiles, tiles_total, grid, lds, s) : hand ? big_launch<U, E, 2, 4, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 2, 4, 0>(a, n_tiles, tiles_total, grid, lds, s);
   return drip ? big_launch<U, E, 2, 2, 9>(a, n_tiles, tiles_total, grid, lds, s) : hand ? big_launch<U, E, 2, 2, 1>(a, n_tiles, tiles_total, grid, lds, s) : big_launch<U, E, 2, 2, 0>(a, n_tiles, tiles_total, grid, lds, s);
+#endif
 }
 
 int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s) {
@@ -676,8 +689,11 @@ int row_panel_linear(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipS
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
     switch (kind) {
-      case 1: return g_big_mode == 1025 ? row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2 | FUSE_ABL_NOLN>(a, f, s)
-                                        : row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2>(a, f, s);
+      case 1:
+#ifdef D3PM_ABLATIONS
+        if (big_gemm_mode() == 1025) return row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2 | FUSE_ABL_NOLN>(a, f, s);
+#endif
+        return row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2>(a, f, s);
       case 2: return row_panel_launch<U, EPI_R2, FUSE_DUAL | FUSE_LN | FUSE_FILM>(a, f, s);
       case 3: return row_panel_launch<U, EPI_R1 | EPI_MASK, FUSE_LN>(a, f, s);
       default: break;

@@ -27,7 +27,7 @@
 namespace d3pm {
 namespace {
 
-constexpr int LT = 64;                       // tile rows and columns of the base geometry
+[[maybe_unused]] constexpr int LT = 64;                       // tile rows and columns of the base geometry
 constexpr int KC = 256;                      // k per round
 // Tile geometries (TM x TN, four waves as 2 x 2): 64 x 64 is the base; 96 x 64 turns the 288 / 384 tiles of the qkv / fc1
 // projections of one utterance (two rounds over 256 CUs at one workgroup per CU) into 192 / 256 (one round, one DMA flight);
@@ -203,6 +203,7 @@ bool panel64_linear_supported(int dtype, const LinearArgs& a) {
   return true;
 }
 
+#ifdef D3PM_ABLATIONS
 const uint16_t* gelu_table_device(hipStream_t s);
 int gelu_table_enabled();
 
@@ -213,13 +214,13 @@ bool panel64_ln_supported(int dtype, const LinearArgs& a, const LnPrologue& ln) 
   if (ln.period && (ln.period % LT != 0 || a.M != 2 * ln.period || ln.film)) return false;
   return aligned16l(ln.w) && aligned16l(ln.b) && aligned16l(ln.w2) && aligned16l(ln.b2) && aligned16l(ln.film);
 }
+#endif
 
-// D3PM_TUNE_LAT_TILE: 0 auto, 1 / 2 / 3 = always 64 x 64 / 96 x 64 / 32 x 64.  Auto: the geometry with the fewest rounds over the
+// d3pm_tuning.lat_tile: 0 auto, 1 / 2 / 3 = always 64 x 64 / 96 x 64 / 32 x 64.  Auto: the geometry with the fewest rounds over the
 // 256 CUs (one workgroup per CU), then the one with the most workgroups (the time of a launch here is the latency of one
 // workgroup's chain -- DMA flight, k-steps, epilogue -- so a round less or a shorter chain is what pays; flops do not matter)
-static int g_lat_tile = 0;
-void set_lat_tile(int v) { g_lat_tile = v; }
 static int lat_geometry(const LinearArgs& a) {
+  const int g_lat_tile = tune_of(a.tune).lat_tile;
   if (g_lat_tile >= 1 && g_lat_tile <= 3) return g_lat_tile - 1;
   static const int tm[3] = {64, 96, 32};
   int best = 0;
@@ -263,10 +264,15 @@ template <typename U, int E> static int panel64_geometry(const LinearArgs& a, co
 }
 
 int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s, const LnPrologue* lnp) {
+#ifdef D3PM_ABLATIONS
   const uint16_t* tab = (a.act == ACT_GELU && dtype == D3PM_BF16 && gelu_table_enabled()) ? gelu_table_device(s) : nullptr;
+#else
+  const uint16_t* tab = nullptr;
+#endif
   const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
+#ifdef D3PM_ABLATIONS
     if (lnp) {
       switch (epi) {
         case 0: return panel64_launch<U, 0, true, 64, 64>(a, lnp, tab, s);
@@ -274,6 +280,9 @@ int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s, const LnProlog
         default: return D3PM_E_SHAPE;
       }
     }
+#else
+    if (lnp) return D3PM_E_SHAPE;
+#endif
     switch (epi) {
       case 0: return panel64_geometry<U, 0>(a, tab, s);
       case EPI_GELU: return panel64_geometry<U, EPI_GELU>(a, tab, s);

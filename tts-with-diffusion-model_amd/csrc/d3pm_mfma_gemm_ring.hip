@@ -16,6 +16,8 @@
 //   * 64-byte rows: 16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3) -- a 16-row fragment read covers one contiguous
 //     KiB, conflict-free; a DMA piece is 16 rows x 64 B;
 //   * same D = W_frag . X_frag^T orientation, same k order and the same epilogue code as the other schedules: bit-identical.
+// Compiled into libd3pm_hip_ab.so only (-DD3PM_ABLATIONS; include/d3pm_hip_ab.h): built, measured, not shipped.
+#ifdef D3PM_ABLATIONS
 #include "d3pm_kernels.h"
 #include "d3pm_mfma_tile.h"
 
@@ -204,3 +206,5 @@ int ring_linear(int dtype, const LinearArgs& a, hipStream_t s) {
 }
 
 }  // namespace d3pm
+
+#endif  // D3PM_ABLATIONS

@@ -13,18 +13,27 @@ import numpy as np
 import torch
 
 F32, F16, BF16 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_GREEDY, FLAG_FORCE_GENERIC, FLAG_SEED_IN_HBM = 1, 2, 4
 K_GEMM, K_ATTN, K_SAMPLE, K_LN, K_GEMM_LN, K_ALL = 0, 1, 2, 3, 4, 5
 
 _DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
-LIB_PATH = os.environ.get("D3PM_HIP_LIB") or os.path.normpath(
-    os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "lib", "libd3pm_hip.so"))
+_LIB_DIR = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "lib"))
+LIB_PATH = os.environ.get("D3PM_HIP_LIB") or os.path.join(_LIB_DIR, "libd3pm_hip.so")
+AB_LIB_PATH = os.path.join(_LIB_DIR, "libd3pm_hip_ab.so")      # the experiment build (include/d3pm_hip_ab.h); tests/ab_*.py only
+
+
+class Tuning(C.Structure):
+    """d3pm_tuning (include/d3pm_hip.h): schedule choices, every value bit-identical.  The C library keeps no state: a
+    pointer to one of these travels in the shape structs.  `TUNING` below is this module's default instance."""
+    _fields_ = [(n, C.c_int32) for n in ("gemm_variant", "gemm_persist_slots", "lat_tile", "attn_query_groups",
+                                         "attn_pair_sequential", "attn_cross_resident", "row_panel", "workspace_alias")] + \
+               [("prof", C.c_void_p)]
 
 
 class Shape(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d_model", "n_heads", "n_layers", "canvas", "s_text", "s_prompt",
-                                         "n_classes", "mask_id", "timesteps", "dtype")]
+                                         "n_classes", "mask_id", "timesteps", "dtype")] + [("tuning", C.POINTER(Tuning))]
 
 
 _BLOCK_FIELDS = ("norm1_w", "norm1_b", "attn_in_w", "attn_in_b", "attn_out_w", "attn_out_b", "norm2_w", "norm2_b",
@@ -63,7 +72,7 @@ class CondWeights(C.Structure):
 
 class NarShape(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d_model", "n_heads", "n_layers", "n_tokens", "n_prom_levels", "n_resp_levels",
-                                         "dtype")]
+                                         "dtype")] + [("tuning", C.POINTER(Tuning))]
 
 
 _NAR_BLOCK_FIELDS = ("attn_norm_emb", "to_qkv_w", "to_out_w", "to_out_b", "ffn_norm_emb", "ffn0_w", "ffn0_b", "ffn3_w",
@@ -128,14 +137,12 @@ SIGNATURES = {
                                  C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "d3pm_op_linear": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 C.c_int, C.c_void_p]),
+                                 C.c_int, C.POINTER(Tuning), C.c_void_p]),
     "d3pm_op_attention": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-                                    C.c_void_p]),
+                                    C.POINTER(Tuning), C.c_void_p]),
     "d3pm_op_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_float, C.c_void_p]),
-    "d3pm_op_linear_lnpro": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "d3pm_op_linear_rowpanel": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
@@ -156,34 +163,66 @@ SIGNATURES = {
     "d3pm_op_embed_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "d3pm_op_embed_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
-    "d3pm_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "d3pm_tuning_default": (None, [C.POINTER(Tuning)]),
+    "d3pm_prof_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "d3pm_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double)]),
+    "d3pm_prof_read_class": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double)]),
+    "d3pm_prof_destroy": (C.c_int, [C.c_void_p]),
+}
+
+# what libd3pm_hip_ab.so exports on top (include/d3pm_hip_ab.h): experiments that were measured and not shipped
+AB_SIGNATURES = {
+    "d3pm_ab_set": (C.c_int, [C.c_int, C.c_int]),
+    "d3pm_op_linear_lnpro": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "d3pm_op_final_sample": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
     "d3pm_debug_gemm_clock": (C.c_int, [C.POINTER(C.c_uint64)]),
-    "d3pm_prof_enable": (C.c_int, [C.c_int, C.c_int]),
-    "d3pm_prof_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                 C.POINTER(C.c_double)]),
-    "d3pm_prof_read_class": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                       C.POINTER(C.c_double)]),
-    "d3pm_prof_disable": (C.c_int, []),
 }
+AB_GEMM_BIG_MODE, AB_ATTN_ARM, AB_GEMM_RING, AB_GELU_TABLE, AB_LN_PROLOGUE, AB_FUSED_FINAL_SAMPLE = range(6)
+_is_ab = False
+TUNING = Tuning()        # filled by d3pm_tuning_default when the library loads
+
+
+def _load(path, signatures):
+    if not os.path.isfile(path):
+        raise RuntimeError(f"{path} is missing: the HIP extension has not been built "
+                           "(run __graft_entry__.build()); there is no CPU fallback")
+    handle = C.CDLL(path)
+    for name, (res, args) in signatures.items():
+        fn = getattr(handle, name)
+        fn.restype, fn.argtypes = res, args
+    if handle.d3pm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{os.path.basename(path)} ABI version mismatch")
+    return handle
 
 
 def lib():
     """The loaded library; raises if it has not been built (no silent fallback)."""
     global _lib
     if _lib is None:
-        if not os.path.isfile(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension has not been built "
-                               "(run __graft_entry__.build()); there is no CPU fallback")
-        handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)
-            fn.restype, fn.argtypes = res, args
-        if handle.d3pm_abi_version() != ABI_VERSION:
-            raise RuntimeError("libd3pm_hip.so ABI version mismatch")
-        _lib = handle
+        _lib = _load(LIB_PATH, SIGNATURES)
+        _lib.d3pm_tuning_default(C.byref(TUNING))
     return _lib
+
+
+def use_ab_library():
+    """A/B scripts only (tests/ab_*.py): route this module to libd3pm_hip_ab.so -- the same sources built with
+    -DD3PM_ABLATIONS (__graft_entry__.build_ab()) -- which also carries the experiments of include/d3pm_hip_ab.h."""
+    global _lib, _is_ab
+    _lib = _load(AB_LIB_PATH, {**SIGNATURES, **AB_SIGNATURES})
+    _lib.d3pm_tuning_default(C.byref(TUNING))
+    _is_ab = True
+    return _lib
+
+
+def _ab_set(knob: int, value: int):
+    if not _is_ab:
+        raise D3PMError("this knob belongs to an experiment that lives in libd3pm_hip_ab.so only: call _hip.use_ab_library() "
+                        "(tests/ab_*.py); the product library has no such path")
+    check(lib().d3pm_ab_set(knob, int(value)), "d3pm_ab_set")
 
 
 class D3PMError(RuntimeError):
@@ -219,9 +258,10 @@ class Schedule:
         self.c_struct = ScheduleC(timesteps, p(self.d), p(self.c), p(self.dbar), p(self.cbar))
 
 
-def make_shape(cfg, dtype: torch.dtype) -> Shape:
+def make_shape(cfg, dtype: torch.dtype, tuning: "Tuning | None" = None) -> Shape:
+    lib()                                             # TUNING holds the library's defaults from here on
     return Shape(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.canvas, cfg.s_text, cfg.s_prompt, cfg.n_classes,
-                 cfg.mask_id, cfg.timesteps, dtype_code(dtype))
+                 cfg.mask_id, cfg.timesteps, dtype_code(dtype), C.pointer(tuning if tuning is not None else TUNING))
 
 
 class DeviceWeights:
@@ -445,6 +485,8 @@ class Sampler:
         B = self._check_grid(x_t)
         _require(hidden, "hidden", (B, cfg.canvas, cfg.d_model), (self.dtype,), self.device)
         x_next = torch.empty_like(x_t)
+        if not _is_ab:
+            raise D3PMError("the fused final + sampler kernel is an experiment of libd3pm_hip_ab.so (use_ab_library())")
         check(lib().d3pm_op_final_sample(C.byref(self.shape), C.byref(self.weights.c_struct), B, _p(hidden), _p(x_t), _p(x_next),
                                          int(t), C.byref(self.schedule.c_struct), seed, utt0, flags, stream_ptr()),
               "d3pm_op_final_sample")
@@ -552,7 +594,7 @@ def op_linear(x, w, bias=None, *, act=0, r1=None, r2=None, row_mask=None, mask_p
     y = torch.zeros((M, ldy), dtype=x.dtype, device=x.device) if out is None else out
     check(lib().d3pm_op_linear(dtype_code(x.dtype), family, _p(x), x.stride(0), _p(w), _p(bias), _p(y), ldy, _p(r1),
                                _p(r2), 0 if r1 is None else r1.stride(0), _p(row_mask), mask_period, M, N, K, act,
-                               stream_ptr()), "d3pm_op_linear")
+                               C.byref(TUNING), stream_ptr()), "d3pm_op_linear")
     return y[:, :N]
 
 
@@ -591,7 +633,8 @@ def op_attention(q, k, v, n_heads, scale, *, family=0):
     assert q.stride(0) == Tq * q.stride(1) and k.stride(0) == S * k.stride(1) and v.stride(0) == S * v.stride(1)
     o = torch.empty((B, Tq, d), dtype=q.dtype, device=q.device)
     check(lib().d3pm_op_attention(dtype_code(q.dtype), family, _p(q), q.stride(1), _p(k), _p(v), k.stride(1), _p(o), d,
-                                  B, Tq, S, n_heads, d // n_heads, float(scale), stream_ptr()), "d3pm_op_attention")
+                                  B, Tq, S, n_heads, d // n_heads, float(scale), C.byref(TUNING), stream_ptr()),
+          "d3pm_op_attention")
     return o
 
 
@@ -610,6 +653,8 @@ def op_linear_lnpro(x, w, bias, ln_w, ln_b, *, ln2_w=None, ln2_b=None, film=None
         raise ValueError("op_linear_lnpro: x [m,512], w [N,512], contiguous")
     M, N = (2 * m if ln2_w is not None else m), w.shape[0]
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if not _is_ab:
+        raise D3PMError("the LayerNorm-prologue GEMM is an experiment of libd3pm_hip_ab.so (use_ab_library())")
     check(lib().d3pm_op_linear_lnpro(dtype_code(x.dtype), _p(x), _p(w), _p(bias), _p(y), M, N, act, _p(ln_w), _p(ln_b), _p(ln2_w),
                                      _p(ln2_b), _p(film), eps, stream_ptr()), "d3pm_op_linear_lnpro")
     return y
@@ -636,8 +681,9 @@ class NarRunner:
 
     def __init__(self, cfg, tensors: dict, dtype: torch.dtype, device, pe: torch.Tensor):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        lib()
         self.shape = NarShape(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.n_tokens, cfg.n_prom_levels, cfg.n_resp_levels,
-                              dtype_code(dtype))
+                              dtype_code(dtype), C.pointer(TUNING))
         self._keep = [pe]
 
         def ptr(key):
@@ -680,87 +726,132 @@ def uniform(seed: int, t: int, row0: int, rows: int, n_classes: int, stream_id: 
     return out
 
 
+# ---- schedule choices: fields of this module's default Tuning (what every Sampler / NarRunner / op_* call passes) --------------
 def set_gemm_variant(v: int):
-    check(lib().d3pm_set_tuning(0, v), "d3pm_set_tuning")
+    if v not in (0, 2, 3, 4, 5, 6, 7, 8):
+        raise D3PMError(f"gemm_variant {v}: not a shipped schedule (include/d3pm_hip.h)")
+    lib()
+    TUNING.gemm_variant = v
 
 
 def set_attn_query_groups(v: int):
-    check(lib().d3pm_set_tuning(1, v), "d3pm_set_tuning")
+    if v not in (0, 1, 2):
+        raise D3PMError(f"attn_query_groups {v}: not a shipped schedule (include/d3pm_hip.h)")
+    lib()
+    TUNING.attn_query_groups = v
 
 
 def set_attn_pair_sequential(v):
     """0 / False never, 1 auto (default), 2 / True always."""
-    check(lib().d3pm_set_tuning(3, 2 if v is True else int(v)), "d3pm_set_tuning")
+    lib()
+    TUNING.attn_pair_sequential = 2 if v is True else int(v)
 
 
 def set_lat_tile(v: int):
-    check(lib().d3pm_set_tuning(10, int(v)), "d3pm_set_tuning")
-
-
-def set_ln_prologue(v: bool):
-    check(lib().d3pm_set_tuning(9, 1 if v else 0), "d3pm_set_tuning")
+    lib()
+    TUNING.lat_tile = int(v)
 
 
 def set_row_panel(mask: int):
-    check(lib().d3pm_set_tuning(8, int(mask)), "d3pm_set_tuning")
-
-
-def set_gelu_table(v: bool):
-    check(lib().d3pm_set_tuning(7, 1 if v else 0), "d3pm_set_tuning")
+    lib()
+    TUNING.row_panel = int(mask)
 
 
 def set_attn_cross_resident(v):
-    """0 / False never, 1 auto (default), 2 / True always."""
-    check(lib().d3pm_set_tuning(6, 2 if v is True else int(v)), "d3pm_set_tuning")
+    """0 / False never, 1 auto (default), 2 / True always, 3 one query block per workgroup."""
+    lib()
+    TUNING.attn_cross_resident = 2 if v is True else int(v)
+
+
+def set_gemm_persist_slots(v: int):
+    lib()
+    TUNING.gemm_persist_slots = int(v)
+
+
+def set_workspace_alias(v: bool):
+    lib()
+    TUNING.workspace_alias = 1 if v else 0
+
+
+def reset_tuning():
+    """Back to the library's defaults (d3pm_tuning_default); an attached profiler stays attached."""
+    prof = TUNING.prof
+    lib().d3pm_tuning_default(C.byref(TUNING))
+    TUNING.prof = prof
+
+
+TUNING_FIELDS = tuple(n for n, _ in Tuning._fields_ if n != "prof")
+
+
+def set_tuning_field(name: str, value: int):
+    """bench.py --tune name=value"""
+    if name not in TUNING_FIELDS:
+        raise D3PMError(f"unknown tuning field {name!r}: one of {TUNING_FIELDS}")
+    lib()
+    setattr(TUNING, name, int(value))
+
+
+# ---- experiments (libd3pm_hip_ab.so only) ------------------------------------------------------------------------------------
+def set_ln_prologue(v: bool):
+    _ab_set(AB_LN_PROLOGUE, 1 if v else 0)
+
+
+def set_gelu_table(v: bool):
+    _ab_set(AB_GELU_TABLE, 1 if v else 0)
 
 
 def set_fused_final_sample(v: bool):
-    check(lib().d3pm_set_tuning(5, 1 if v else 0), "d3pm_set_tuning")
+    _ab_set(AB_FUSED_FINAL_SAMPLE, 1 if v else 0)
 
 
 def set_gemm_big_mode(v: int):
-    check(lib().d3pm_set_tuning(4, v), "d3pm_set_tuning")
+    _ab_set(AB_GEMM_BIG_MODE, v)
+
+
+def set_attn_arm(v: int):
+    _ab_set(AB_ATTN_ARM, v)
+
+
+def set_gemm_ring(v: bool):
+    _ab_set(AB_GEMM_RING, 1 if v else 0)
 
 
 def gemm_clock_ghz() -> float:
     """Shader clock (GHz) held during the last big-tile GEMM launched with big mode bit 8 set; synchronises."""
+    if not _is_ab:
+        raise D3PMError("d3pm_debug_gemm_clock lives in libd3pm_hip_ab.so (use_ab_library())")
     torch.cuda.synchronize()
     buf = (C.c_uint64 * 2)()
     check(lib().d3pm_debug_gemm_clock(buf), "d3pm_debug_gemm_clock")
     return buf[0] / max(buf[1], 1) * 0.1
 
 
-def set_gemm_persist_slots(v: int):
-    check(lib().d3pm_set_tuning(2, v), "d3pm_set_tuning")
-
-
-_PROFILING = False
-
-
+# ---- timing hooks: a d3pm_prof handle attached to the default Tuning ------------------------------------------------------
 def prof_enable(kclass: int, max_events: int):
-    global _PROFILING
-    check(lib().d3pm_prof_enable(kclass, max_events), "d3pm_prof_enable")
-    _PROFILING = True
+    prof_disable()
+    h = C.c_void_p()
+    check(lib().d3pm_prof_create(kclass, max_events, C.byref(h)), "d3pm_prof_create")
+    TUNING.prof = h.value
 
 
 def prof_read():
     n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
-    check(lib().d3pm_prof_read(C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "d3pm_prof_read")
+    check(lib().d3pm_prof_read(TUNING.prof, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "d3pm_prof_read")
     return n.value, ms.value, fl.value, by.value
 
 
 def prof_read_class(kclass: int):
     """(launches, total ms, algorithmic flops, algorithmic bytes) of one kernel class; does not reset."""
     n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
-    check(lib().d3pm_prof_read_class(kclass, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "d3pm_prof_read_class")
+    check(lib().d3pm_prof_read_class(TUNING.prof, kclass, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "d3pm_prof_read_class")
     return n.value, ms.value, fl.value, by.value
 
 
 def prof_disable():
-    global _PROFILING
-    lib().d3pm_prof_disable()
-    _PROFILING = False
+    if TUNING.prof:
+        lib().d3pm_prof_destroy(TUNING.prof)
+        TUNING.prof = None
 
 
 def profiling() -> bool:
-    return _PROFILING
+    return bool(TUNING.prof)
