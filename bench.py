@@ -163,17 +163,22 @@ def fp8_fast_path(dev, dtype, batch, cfg, sd32, texts, proms):
     for name, fp8 in (("bf16_50_steps", False), ("fp8_50_steps", True)):
         m.generate_audio(texts, proms, seed=1, fp8=fp8)
         torch.cuda.synchronize()
+        reps = 6
         t0 = time.perf_counter()
-        for i in range(2):
+        for i in range(reps):
             ids[name] = m.generate_audio(texts, proms, seed=7, fp8=fp8)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 2
-        out[name] = {"seconds_per_batch": dt, "codec_tokens_per_s": batch * cfg.n_frames / dt}
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"seconds_per_batch": dt, "codec_tokens_per_s": batch * cfg.n_frames / dt, "repetitions": reps}
     live = slice(0, cfg.n_frames)
     a, b = (ids[k].reshape(batch, -1)[:, live] for k in ("bf16_50_steps", "fp8_50_steps"))     # one utterance comes back 1-D
     out["id_agreement_fp8_vs_bf16"] = float((a == b).float().mean())
+    out["speedup_fp8_vs_bf16_same_schedule"] = out["fp8_50_steps"]["codec_tokens_per_s"] / out["bf16_50_steps"]["codec_tokens_per_s"]
     out["note"] = ("49 iterations (timesteps = 50), same synthetic weights except time_emb (random init for the shorter "
-                   "schedule); fp8 = e4m3 rows / channels with fp32 scales for norm1->QKV, norm2|22->cross q, norm3->fc1")
+                   "schedule); fp8 = block-scaled e4m3 (v_mfma_scale_f32_16x16x128_f8f6f4, one power-of-two scale per 32 elements) "
+                   "for norm1->QKV, norm2|22->cross q, norm3->fc1 (GELU epilogue writes the hidden layer in that format) and fc2; "
+                   "free-running id agreement compounds single near-tie flips over 49 iterations (teacher-forced agreement and "
+                   "logits error: tests/test_gpu_parity.py::test_fp8_fast_path_agreement_with_the_16_bit_path)")
     return out
 
 

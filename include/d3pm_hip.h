@@ -143,13 +143,19 @@ typedef struct d3pm_weights {
   const d3pm_block_weights *blocks;       /* HOST array of n_layers entries               */
 } d3pm_weights;
 
-/* e4m3 copies of the three LayerNorm-fed K = d projection weights of one block for the fp8 fast path (BASELINE.json
- * configs[4]; built by the caller, e.g. _hip.quantize_rows_e4m3): codes [N][d] one byte per element, row-major, and one
- * fp32 scale per output channel (W[n][k] ~ code[n][k] * scale[n]).  cross_in covers the q rows only ([d][d]). */
+/* Block-scaled fp8 ("MX": OCP e4m3 codes + one e8m0 power-of-two scale per 32 elements along K) copies of a block's
+ * projection weights for the fp8 fast path (BASELINE.json configs[4]; built by the caller, e.g. _hip.quantize_mx):
+ *   codes  [N][K] one byte per element, row-major;
+ *   scales [N][4][K / 128] bytes, value 2^(byte - 127): scales[n][g][s] applies to elements [128 s + 32 g, 128 s + 32 g + 32)
+ *          of row n (g-major so that the matrix instruction's lane fetches four consecutive k-steps of its block as one dword;
+ *          csrc/d3pm_mx.hip).
+ * cross_in covers the q rows only ([d][d]).  fc2_w8 / fc2_scale may be NULL: then fc1 writes a 16-bit hidden layer and fc2
+ * stays a 16-bit GEMM. */
 typedef struct d3pm_fp8_block_weights {
-  const void *attn_in_w8;  const float *attn_in_scale;    /* [3d][d], [3d] */
-  const void *cross_in_w8; const float *cross_in_scale;   /* [d][d],  [d]  */
-  const void *fc1_w8;      const float *fc1_scale;        /* [4d][d], [4d] */
+  const void *attn_in_w8;  const void *attn_in_scale;    /* [3d][d], [3d][4][d/128]   */
+  const void *cross_in_w8; const void *cross_in_scale;   /* [d][d],  [d][4][d/128]    */
+  const void *fc1_w8;      const void *fc1_scale;        /* [4d][d], [4d][4][d/128]   */
+  const void *fc2_w8;      const void *fc2_scale;        /* [d][4d], [d][4][4d/128] or NULL */
 } d3pm_fp8_block_weights;
 
 /* fp16 bit patterns of the absorbing-state schedule, HOST arrays.
@@ -255,12 +261,14 @@ int d3pm_sample_loop(const d3pm_shape *shape, const d3pm_weights *w, int batch, 
                      uint64_t seed, uint32_t utt0, uint32_t flags, void *workspace,
                      size_t workspace_bytes, int32_t *trace, void *stream);
 
-/* The fp8 fast path (BASELINE.json configs[4]): same contracts as d3pm_denoise_step / d3pm_sample_loop, but norm1 ->
- * QKV, norm2|norm22 -> the merged cross-attention query projection and norm3(+FiLM) -> fc1 run with e4m3 operands
- * (LayerNorm rows quantised per row on the fly, weights per output channel from `fp8_blocks`, a HOST array of
- * n_layers entries; fp32 accumulation, 16-bit outputs).  Requires d_model = 512, a 16-bit model dtype and
- * batch * canvas a multiple of 128; otherwise (and under D3PM_FLAG_FORCE_GENERIC) the 16-bit path runs.  The reference
- * has no such mode: tests report agreement against the 16-bit path. */
+/* The fp8 fast path (BASELINE.json configs[4]): same contracts as d3pm_denoise_step / d3pm_sample_loop, but the K = d_model
+ * projections fed by a LayerNorm -- norm1 -> QKV, norm2|norm22 -> the merged cross-attention query projection, norm3(+FiLM) ->
+ * fc1 -- and (when fc2_w8 is given) fc2 run on the block-scaled matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4 with
+ * e4m3 operands: LayerNorm rows are quantised on the fly in blocks of 32 (power-of-two scales), fc1's GELU epilogue writes
+ * its output directly in that format for fc2, weights come from `fp8_blocks` (a HOST array of n_layers entries); fp32
+ * accumulation, 16-bit residual stream.  Requires d_model = 512, a 16-bit model dtype and batch * canvas a multiple of 192;
+ * D3PM_E_SHAPE otherwise (and D3PM_E_ARG under D3PM_FLAG_FORCE_GENERIC): a number labelled fp8 is never a 16-bit run.  The
+ * reference has no such mode: tests report agreement against the 16-bit path. */
 int d3pm_denoise_step_fp8(const d3pm_shape *shape, const d3pm_weights *weights,
                           const d3pm_fp8_block_weights *fp8_blocks, int batch, const int32_t *x_t,
                           const uint8_t *frame_mask, int t, const void *film, const void *kv_text,
@@ -343,15 +351,22 @@ int d3pm_nar_level(const d3pm_nar_shape *shape, const d3pm_nar_weights *w, int b
 int d3pm_op_linear(int dtype, int family, const void *X, int ldx, const void *W, const void *bias, void *Y,
                    int ldy, const void *R1, const void *R2, int ldr, const uint8_t *row_mask,
                    int mask_period, int M, int N, int K, int act, const d3pm_tuning *tuning, void *stream);
-/* fp8 (OCP e4m3) fast path, BASELINE.json configs[4] (no reference counterpart: the reference is fp16 only):
- *   layernorm_fp8: Y8[M][512] = e4m3(LN(X)*w + b [FiLM] / sx[m]), sx[m] = absmax of the row / 448 (fp32), the 16-bit
- *                  LayerNorm result being exactly d3pm_op_layernorm's;
- *   linear_fp8:    Y[M][N] = epilogue((X8 . W8^T) * sx[m] * sw[n] + bias) in `out_dtype` (f16 / bf16), fp32 accumulate,
- *                  act 0 none / 1 GELU; M, N, K multiples of 128, X8 / W8 row-major one byte per element. */
-int d3pm_op_linear_fp8(int out_dtype, const void *X8, int ldx, const float *sx, const void *W8, const float *sw,
-                       const void *bias, void *Y, int ldy, int M, int N, int K, int act, void *stream);
-int d3pm_op_layernorm_fp8(int dtype, const void *X, void *Y8, float *sx, const void *w, const void *b,
-                          const void *film, int M, int d, float eps, void *stream);
+/* Block-scaled fp8 single ops (BASELINE.json configs[4]; no reference counterpart: the reference is fp16 only).  Formats as
+ * in d3pm_fp8_block_weights: codes [rows][K], scales [rows][4][K / 128].
+ *   quantize_mx:   any 16-bit X [M][K] (K a multiple of 128) -> X8, SX; scale of a block = the smallest power of two with
+ *                  absmax / scale <= 448, codes = rn_e4m3(x / scale) (never saturate);
+ *   layernorm_mx:  Y8 [M][512], SX [M][4][4] = quantize_mx(LN(X) * w + b [FiLM]), the 16-bit LayerNorm result being exactly
+ *                  d3pm_op_layernorm's;
+ *   linear_mx:     epilogue(sum_k X8 2^sx . W8 2^sw + bias) with fp32 accumulation: act 0 none / 1 GELU, optional residual
+ *                  R1 [M][N] and row mask as d3pm_op_linear, 16-bit output Y [M][ldy] in `out_dtype` -- or, with Y8 / SY given
+ *                  (R1 = row_mask = NULL, Y ignored), the output itself in the MX format: Y8 [M][N], SY [M][4][N / 128].
+ *                  M a multiple of 192, N of 128, K of 512. */
+int d3pm_op_quantize_mx(int dtype, const void *X, int ldx, void *X8, void *SX, int M, int K, void *stream);
+int d3pm_op_layernorm_mx(int dtype, const void *X, void *Y8, void *SX, const void *w, const void *b, const void *film, int M,
+                         int d, float eps, void *stream);
+int d3pm_op_linear_mx(int out_dtype, const void *X8, int ldx, const void *SX, const void *W8, const void *SW, const void *bias,
+                      void *Y, int ldy, const void *R1, int ldr, const uint8_t *row_mask, int mask_period, void *Y8, void *SY,
+                      int M, int N, int K, int act, void *stream);
 int d3pm_op_attention(int dtype, int family, const void *Q, int ldq, const void *K, const void *V, int ldkv,
                       void *O, int ldo, int B, int Tq, int S, int H, int hd, float scale, const d3pm_tuning *tuning,
                       void *stream);

@@ -1,4 +1,5 @@
-"""fp8 vs bf16 GEMM on the LayerNorm-fed shapes, interleaved in one process."""
+"""Block-scaled fp8 (MX) vs bf16 GEMM on the projections of a DiT block at the bench batch, interleaved in one process
+(not a test): python tests/ab_fp8.py"""
 import math, statistics, sys, torch
 sys.path.insert(0, "tts-with-diffusion-model_amd")
 from vall_e.vall_e import _hip
@@ -14,16 +15,20 @@ def timeit(f, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for name, M, N, K, act in (("qkv", 24576, 1536, 512, 0), ("merged-q", 49152, 512, 512, 0), ("fc1+gelu", 24576, 2048, 512, 1)):
+SHAPES = (("qkv", 24576, 1536, 512, 0, False, False), ("merged-q", 49152, 512, 512, 0, False, False),
+          ("fc1+gelu", 24576, 2048, 512, 1, False, False), ("fc1+gelu->mx", 24576, 2048, 512, 1, False, True),
+          ("fc2+res", 24576, 512, 2048, 0, True, False))
+for name, M, N, K, act, res, mx_out in SHAPES:
     x = torch.randn(M, K, device=DEV).to(dtype); w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(dtype)
     b = torch.randn(N, device=DEV).to(dtype); y = torch.empty(M, N, device=DEV, dtype=dtype)
-    x8, sx = _hip.quantize_rows_e4m3(x); w8, sw = _hip.quantize_rows_e4m3(w)
-    f16 = lambda: _hip.op_linear(x, w, b, act=act, family=_hip.FAMILY_MFMA, out=y, ldy=N)
-    f8 = lambda: _hip.op_linear_fp8(x8, sx, w8, sw, b, dtype, act=act)
+    r = torch.randn(M, N, device=DEV).to(dtype) if res else None
+    x8, sx = _hip.op_quantize_mx(x); w8, sw = _hip.quantize_mx(w)
+    f16 = lambda: _hip.op_linear(x, w, b, act=act, r1=r, family=_hip.FAMILY_MFMA, out=y, ldy=N)
+    f8 = lambda: _hip.op_linear_mx(x8, sx, w8, sw, b, dtype, act=act, r1=r, mx_out=mx_out)
     t16, t8 = [], []
     for rep in range(7):
         t16.append(timeit(f16)); t8.append(timeit(f8))
-    print(f"{name:9s} bf16 {statistics.median(t16):7.1f} us | fp8 {statistics.median(t8):7.1f} us", flush=True)
-g = torch.Generator(device="cpu").manual_seed(0)
+    a, c = statistics.median(t16), statistics.median(t8)
+    print(f"{name:13s} bf16 {a:7.1f} us {2 * M * N * K / a / 1e6:6.0f} TF/s | mx-fp8 {c:7.1f} us {2 * M * N * K / c / 1e6:6.0f} TF/s | x{a / c:4.2f}", flush=True)
 x = torch.randn(24576, 512, device=DEV).to(dtype); w = torch.ones(512, device=DEV, dtype=dtype); b = torch.zeros(512, device=DEV, dtype=dtype)
-print(f"layernorm bf16 {timeit(lambda: _hip.op_layernorm(x, w, b)):6.1f} us | fp8 rows {timeit(lambda: _hip.op_layernorm_fp8(x, w, b)):6.1f} us")
+print(f"layernorm bf16 {timeit(lambda: _hip.op_layernorm(x, w, b)):6.1f} us | -> mx rows {timeit(lambda: _hip.op_layernorm_mx(x, w, b)):6.1f} us")

@@ -257,7 +257,33 @@ def test_layernorm_and_film(built_lib, dtype):
 
 # ---- fp8 (OCP e4m3) fast path, BASELINE.json configs[4]: no reference counterpart, pinned to torch on the SAME codes ----
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_layernorm_fp8_is_the_layernorm_then_a_row_scale(built_lib, dtype):
+def test_quantize_mx_is_the_block_rule(built_lib, dtype):
+    """d3pm_op_quantize_mx (blocks of 32 along K, power-of-two scales, e4m3 codes) against the same rule in torch
+    (_hip.quantize_mx): scales and codes bit for bit, incl. blocks of very different magnitude, all-zero blocks and a block
+    whose maximum sits exactly on the 448 / 1.75 boundary of the exponent choice."""
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, K = 384, 2048
+    x = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-12, 12, (M, K // 32), generator=g).float()).repeat_interleave(32, dim=1)
+    x[3] = 0
+    x[4, :32] = 0
+    x[5, :32] = torch.tensor([1.75 * 2.0 ** -3] + [0.01] * 31)        # amax = 1.75 x 2^E exactly: scale 2^(E - 8), code 448
+    x[6, :32] = torch.tensor([1.8125 * 2.0 ** -3] + [0.01] * 31)      # just above: the next power of two
+    x = x.to(dtype).to(DEV)
+    x8, sx = _hip.op_quantize_mx(x)
+    r8, rs = _hip.quantize_mx(x)
+    assert sx.shape == (M, 4, K // 128) and torch.equal(sx, rs)
+    assert torch.equal(x8, r8), f"{(x8 != r8).float().mean().item():.2e} of the codes differ"
+    deq = _hip.dequantize_mx(x8, sx)
+    xf = x.float()
+    blockmax = xf.abs().reshape(M, K // 32, 32).amax(dim=-1).repeat_interleave(32, dim=1)
+    assert ((deq - xf).abs() <= 0.0625 * xf.abs() + 2.0 ** -9 * blockmax + 1e-30).all()      # e4m3: 3 mantissa bits, 2^-9 of the block scale x 448
+    assert x8[5, 0].item() == 0x7E and x8[6, 0].item() < 0x7E                               # 448 = 0x7E; never the NaN code 0x7F
+    assert (x8 & 0x7F).max().item() <= 0x7E
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layernorm_mx_is_the_layernorm_then_the_block_rule(built_lib, dtype):
     from vall_e.vall_e import _hip
     g = torch.Generator(device="cpu").manual_seed(21)
     M, d = 1024, 512
@@ -267,35 +293,61 @@ def test_layernorm_fp8_is_the_layernorm_then_a_row_scale(built_lib, dtype):
     b = (0.1 * torch.randn(d, generator=g)).to(dtype).to(DEV)
     film = (0.2 * torch.randn(2 * d, generator=g)).to(dtype).to(DEV)
     for fl in (None, film):
-        y16 = _hip.op_layernorm(x, w, b, film=fl)                      # the 16-bit result the fp8 row is derived from
-        y8, sx = _hip.op_layernorm_fp8(x, w, b, film=fl)
-        amax = y16.float().abs().amax(dim=1)
-        ref_scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-        assert torch.allclose(sx, ref_scale, rtol=1e-6, atol=0)
-        codes = y8.view(torch.float8_e4m3fn).float()
-        ref_codes = (y16.float() / ref_scale[:, None]).to(torch.float8_e4m3fn).float()
-        assert (codes != ref_codes).float().mean().item() < 2e-3        # ties of the 1/scale rounding aside, the same codes
-        deq = codes * sx[:, None]
-        assert ((deq - y16.float()).abs() <= 0.0665 * y16.float().abs() + 2e-3 * amax[:, None]).all()   # e4m3: 3 mantissa bits
+        y16 = _hip.op_layernorm(x, w, b, film=fl)                      # the 16-bit result the MX row is derived from
+        y8, sx = _hip.op_layernorm_mx(x, w, b, film=fl)
+        r8, rs = _hip.quantize_mx(y16)
+        assert torch.equal(sx, rs) and torch.equal(y8, r8)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,K,act", [(1024, 1536, 512, 0), (2048, 2048, 512, 1), (24576, 1536, 512, 0), (1024, 512, 2048, 0)])
-def test_linear_fp8_against_fp32_on_the_same_codes(built_lib, dtype, M, N, K, act):
-    """Products of two e4m3 numbers are exact in fp32, so the kernel must reproduce a torch fp32 evaluation of the
-    de-quantised operands up to summation order and the final 16-bit rounding."""
+@pytest.mark.parametrize("M,N,K,epi", [(192, 256, 512, "bias"), (384, 128, 512, "bias"), (1920, 1536, 512, "bias"), (2304, 2048, 512, "gelu"),
+                                       (768, 512, 2048, "r1mask"), (960, 512, 2048, "r1"), (24576, 1536, 512, "bias"), (576, 384, 1024, "nobias")])
+def test_linear_mx_against_fp32_on_the_same_codes(built_lib, dtype, M, N, K, epi):
+    """Products of two e4m3 numbers and power-of-two scales are exact in fp32, so the block-scaled kernel must reproduce a torch
+    fp32 evaluation of the de-quantised operands up to summation order and the final 16-bit rounding.  The operands carry
+    blocks of very different magnitude (2^-6 .. 2^6 per 32 elements): a scale applied to the wrong block, row or k-step -- the
+    lane / op_sel map of v_mfma_scale_f32_16x16x128_f8f6f4 -- shows up as an O(1) error.  Twice: a race between the DMA pieces
+    and the fragment reads would not repeat."""
     from vall_e.vall_e import _hip
-    g = torch.Generator(device="cpu").manual_seed(M + N + act)
-    x8, sx = _hip.quantize_rows_e4m3(torch.randn(M, K, generator=g).to(DEV))
-    w8, sw = _hip.quantize_rows_e4m3((torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV))
-    b = (torch.randn(N, generator=g) * 0.1).to(dtype).to(DEV)
-    y = _hip.op_linear_fp8(x8, sx, w8, sw, b, dtype, act=act)
-    xf = x8.view(torch.float8_e4m3fn).float() * sx[:, None]
-    wf = w8.view(torch.float8_e4m3fn).float() * sw[:, None]
-    ref = xf @ wf.T + b.float()
-    if act:
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    T = 96
+
+    def blocky(r, c, sc):
+        return torch.randn(r, c, generator=g) * sc * torch.exp2(torch.randint(-6, 7, (r, c // 32), generator=g).float()).repeat_interleave(32, dim=1)
+    x8, sx = _hip.quantize_mx(blocky(M, K, 1.0).to(DEV))
+    w8, sw = _hip.quantize_mx(blocky(N, K, 1.0 / math.sqrt(K)).to(DEV))
+    b = None if epi == "nobias" else (torch.randn(N, generator=g) * 0.1).to(dtype).to(DEV)
+    r1 = torch.randn(M, N, generator=g).to(dtype).to(DEV) if epi.startswith("r1") else None
+    mask = (torch.rand(T, generator=g) < 0.8).to(torch.uint8).to(DEV) if epi == "r1mask" else None
+    y = _hip.op_linear_mx(x8, sx, w8, sw, b, dtype, act=1 if epi == "gelu" else 0, r1=r1, row_mask=mask, mask_period=T)
+    y2 = _hip.op_linear_mx(x8, sx, w8, sw, b, dtype, act=1 if epi == "gelu" else 0, r1=r1, row_mask=mask, mask_period=T)
+    assert torch.equal(y, y2)
+    ref = _hip.dequantize_mx(x8, sx) @ _hip.dequantize_mx(w8, sw).T + (b.float() if b is not None else 0)
+    if epi == "gelu":
         ref = torch.nn.functional.gelu(ref.to(dtype).float())
-    assert_close_lp(y, ref, dtype, f"fp8 linear {M}x{N}x{K} act{act}")
+    if r1 is not None:
+        ref = (ref.to(dtype).float() + r1.float())
+    if mask is not None:
+        ref = ref * mask.float().repeat(M // T)[:, None]
+    assert_close_lp(y, ref, dtype, f"mx linear {M}x{N}x{K} {epi}")
+    if epi in ("bias", "gelu", "nobias"):
+        # the MX-output epilogue (fc1 -> fc2) quantises exactly the 16-bit value the plain epilogue stores
+        y8, sy = _hip.op_linear_mx(x8, sx, w8, sw, b, dtype, act=1 if epi == "gelu" else 0, mx_out=True)
+        r8, rs = _hip.quantize_mx(y)
+        assert torch.equal(sy, rs) and torch.equal(y8, r8)
+
+
+def test_linear_mx_rejects_what_it_cannot_run(built_lib):
+    from vall_e.vall_e import _hip
+    x8 = torch.zeros(100, 512, dtype=torch.uint8, device=DEV)
+    sx = torch.zeros(100, 4, 4, dtype=torch.uint8, device=DEV)
+    w8 = torch.zeros(256, 512, dtype=torch.uint8, device=DEV)
+    sw = torch.zeros(256, 4, 4, dtype=torch.uint8, device=DEV)
+    with pytest.raises(_hip.D3PMError):
+        _hip.op_linear_mx(x8, sx, w8, sw, None, torch.bfloat16)            # M = 100 is not a multiple of 192
+
+
+
 
 
 

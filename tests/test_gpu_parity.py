@@ -504,9 +504,11 @@ def test_ce_loss_rows_against_torch(n32, dtype):
 
 
 def test_fp8_fast_path_agreement_with_the_16_bit_path():
-    """BASELINE.json configs[4] (fp8 QKV/FFN operands, 50-step schedule): no reference counterpart exists, so the test
-    reports agreement against the bf16 path on the same inputs -- logits, teacher-forced sampled ids (same x_t, same
-    noise) and the free-running 49-iteration loop -- and checks the mode is deterministic and really engaged."""
+    """BASELINE.json configs[4] (block-scaled fp8 QKV / cross-query / fc1 / fc2 operands, 50-step schedule): no reference
+    counterpart exists, so the test reports agreement against the bf16 path on the same inputs -- logits, teacher-forced
+    sampled ids (same x_t, same noise) and the free-running 49-iteration loop -- and checks the mode is deterministic and
+    really engaged.  Asserted quality: logits relative L2 error <= 0.03, teacher-forced id agreement >=
+    0.999; both forms of the mode are measured: fc2 on MX operands too (the shipped fast path) and fc2 left 16-bit."""
     import dataclasses
     from vall_e.vall_e import synth
     cfg = dataclasses.replace(synth.D3PMConfig.libritts(), timesteps=50)
@@ -519,20 +521,22 @@ def test_fp8_fast_path_agreement_with_the_16_bit_path():
     x[:, ::2] = torch.randint(0, 1024, x[:, ::2].shape, device=x.device, dtype=x.dtype)      # a half-denoised canvas
     t = 25
     l16, _ = smp.denoise(x, fm, t, kv_t, kv_p)
-    l8, _ = smp.denoise(x, fm, t, kv_t, kv_p, fp8=True)
-    assert not torch.equal(l16, l8)                                   # the fp8 kernels ran
     live = slice(0, cfg.n_frames)
-    d = (l8.float() - l16.float())[:, live]
-    rel = d.norm().item() / l16.float()[:, live].norm().item()
-    top1 = (l8[:, live].float().argmax(-1) == l16[:, live].float().argmax(-1)).float().mean().item()
     n16, _ = smp.posterior_sample(l16, x, t, seed=5)
-    n8, _ = smp.posterior_sample(l8, x, t, seed=5)
-    forced = (n16[:, live] == n8[:, live]).float().mean().item()
     a16 = m.generate_audio(texts, proms, seed=9)[:, live]
-    a8 = m.generate_audio(texts, proms, seed=9, fp8=True)[:, live]
-    free = (a16 == a8).float().mean().item()
-    REPORT["fp8_fast_path"] = {"logits_rel_l2_err": rel, "logits_top1_agreement": top1, "teacher_forced_id_agreement": forced,
-                               "free_running_49_iterations_id_agreement": free}
-    assert rel < 0.05 and forced > 0.9
+    for tag, fc2 in (("fp8_fast_path_fc2_16bit", False), ("fp8_fast_path", True)):
+        smp.fp8_fc2, smp._fp8 = fc2, None                              # (re-)quantise the weights for this form
+        l8, _ = smp.denoise(x, fm, t, kv_t, kv_p, fp8=True)
+        assert not torch.equal(l16, l8)                                   # the fp8 kernels ran
+        d = (l8.float() - l16.float())[:, live]
+        rel = d.norm().item() / l16.float()[:, live].norm().item()
+        top1 = (l8[:, live].float().argmax(-1) == l16[:, live].float().argmax(-1)).float().mean().item()
+        n8, _ = smp.posterior_sample(l8, x, t, seed=5)
+        forced = (n16[:, live] == n8[:, live]).float().mean().item()
+        a8 = m.generate_audio(texts, proms, seed=9, fp8=True)[:, live]
+        free = (a16 == a8).float().mean().item()
+        REPORT[tag] = {"logits_rel_l2_err": rel, "logits_top1_agreement": top1, "teacher_forced_id_agreement": forced,
+                       "free_running_49_iterations_id_agreement": free}
+        assert rel <= 0.03 and forced >= 0.999, (tag, rel, forced)
     assert torch.equal(a8, m.generate_audio(texts, proms, seed=9, fp8=True)[:, live])
     assert int(a8.min()) >= 0 and int(a8.max()) <= 1024

@@ -186,3 +186,27 @@ def test_inputs_are_padded_truncated_and_validated_like_upstream():
         m.generate_audio([], [])
     with pytest.raises(ValueError):
         m.generate_audio([short], [prom, prom])
+
+
+def test_mx_quantiser_layout_and_error_bound():
+    """_hip.quantize_mx / dequantize_mx (the host side of the block-scaled fp8 path): codes [N, K], scales [N, 4, K / 128] with
+    scales[n][g][s] <-> elements [128 s + 32 g, +32); the scale is the smallest power of two that keeps the block inside e4m3."""
+    from vall_e.vall_e import _hip
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(6, 256, generator=g) * torch.exp2(torch.randint(-5, 6, (6, 8), generator=g).float()).repeat_interleave(32, dim=1)
+    w[0, 32:64] = 0
+    codes, sc = _hip.quantize_mx(w)
+    assert codes.shape == (6, 256) and codes.dtype == torch.uint8 and sc.shape == (6, 4, 2) and sc.dtype == torch.uint8
+    for n in range(6):
+        for blk in range(8):
+            amax = w[n, 32 * blk: 32 * blk + 32].abs().max().item()
+            byte = int(sc[n, blk % 4, blk // 4])
+            if amax == 0:
+                assert byte == 1
+                continue
+            scale = 2.0 ** (byte - 127)
+            assert amax / scale <= 448.0 < amax / (scale / 2)
+    deq = _hip.dequantize_mx(codes, sc)
+    bm = w.abs().reshape(6, 8, 32).amax(dim=-1).repeat_interleave(32, dim=1)
+    assert ((deq - w).abs() <= 0.0625 * w.abs() + 2.0 ** -9 * bm).all()
+    assert (codes & 0x7F).max().item() <= 0x7E

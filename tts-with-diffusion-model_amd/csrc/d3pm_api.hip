@@ -210,17 +210,31 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
   const int dt = sh.dtype, d = sh.d_model, H = sh.n_heads, hd = d / H, T = sh.canvas;
   const int n = batch * T;
   const Ctx cx(sh.tuning);
+  const size_t es = dtype_size(dt);
   // fp8 fast path (BASELINE.json configs[4]): the three LayerNorm-fed K = d projections take e4m3 operands; the e4m3 rows
   // and their scales live where the 16-bit LayerNorm outputs would (ws.h | ws.h2 are adjacent: 2 n d 2 bytes)
   const bool use8 = f8 != nullptr;
   if (use8) {   // the *_fp8 entry points never fall back to the 16-bit kernels silently: a number labelled fp8 is fp8
     D3PM_REQUIRE(!(flags & D3PM_FLAG_FORCE_GENERIC), D3PM_E_ARG, "fp8 fast path: D3PM_FLAG_FORCE_GENERIC selects the 16-bit generic kernels");
-    D3PM_REQUIRE(d == 512 && fp8_linear_supported(dt, n, 3 * d, d, d, 3 * d) && ws.h2 == at(ws.h, static_cast<size_t>(n) * d, dtype_size(dt)),
-                 D3PM_E_SHAPE, "fp8 fast path needs d_model = 512, a 16-bit model dtype and batch * canvas (%d) a multiple of 128", n);
+    D3PM_REQUIRE(d == 512 && (dt == D3PM_F16 || dt == D3PM_BF16) && n % 192 == 0 && ws.h2 == at(ws.h, static_cast<size_t>(n) * d, dtype_size(dt)),
+                 D3PM_E_SHAPE, "fp8 fast path needs d_model = 512, a 16-bit model dtype and batch * canvas (%d) a multiple of 192", n);
   }
+  // MX operands of the LayerNorm-fed projections live where the 16-bit LayerNorm outputs would: codes [2n][512] fill ws.h,
+  // their block scales [2n][16] start at ws.h2; fc1's MX output (codes [n][2048] + scales [n][64]) lives in ws.mlp
   uint8_t* x8 = reinterpret_cast<uint8_t*>(ws.h);
-  float* sx8 = reinterpret_cast<float*>(ws.h2);     // 2 n floats at most (n d 2 bytes available)
-  const size_t es = dtype_size(dt);
+  uint8_t* sx8 = reinterpret_cast<uint8_t*>(ws.h2);
+  uint8_t* h8 = reinterpret_cast<uint8_t*>(ws.mlp);
+  uint8_t* sh8 = h8 + static_cast<size_t>(n) * 4 * d;
+  auto mx_gemm = [&](const uint8_t* X8, int ldx8, const uint8_t* SX8, const void* W8, const void* SW8, const void* bias, void* Y, int ldy,
+                     const void* R1, const uint8_t* mask, int period, uint8_t* Y8, uint8_t* SY, int M, int N, int K, int act) -> int {
+    MxLinearArgs m;
+    m.X8 = X8; m.ldx = ldx8; m.SX = SX8; m.W8 = W8; m.SW = SW8; m.bias = bias; m.Y = Y; m.ldy = ldy; m.R1 = R1; m.ldr = ldy;
+    m.row_mask = mask; m.mask_period = period; m.Y8 = Y8; m.SY = SY; m.M = M; m.N = N; m.K = K; m.act = act;
+    D3PM_REQUIRE(mx_linear_supported(dt, m), D3PM_E_SHAPE, "fp8 fast path: block-scaled GEMM %d x %d x %d not supported", M, N, K);
+    ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * M * N * K,
+                1.03125 * (static_cast<double>(M) * K + static_cast<double>(N) * K) + static_cast<double>(M) * N * (Y8 ? 1.03125 : (R1 ? 2.0 : 1.0) * es));
+    return mx_linear(dt, m, s);
+  };
   const float scale = static_cast<float>(std::sqrt(1.0 / static_cast<double>(hd)));
 
   EmbedArgs e;
@@ -265,10 +279,12 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     g.X = ws.h; g.ldx = d; g.W = b.attn_in_w; g.bias = b.attn_in_b; g.Y = ws.qkv; g.ldy = 3 * d;
     g.M = n; g.N = 3 * d; g.K = d;
     if (use8) {
-      D3PM_TRY(layernorm_fp8(dt, ws.x, x8, sx8, b.norm1_w, b.norm1_b, nullptr, nullptr, nullptr, nullptr, nullptr, n, d, 1e-6f, s));
-      ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * g.M * g.N * g.K, 1.0 * g.M * g.K + 1.0 * g.N * g.K + es * g.M * g.N);
-      D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].attn_in_w8), f8[l].attn_in_scale, b.attn_in_b, ws.qkv,
-                          3 * d, n, 3 * d, d, ACT_NONE, s));
+      {
+        ProfScope p(cx, D3PM_K_LN, s, 0.0, static_cast<double>(n) * d * (es + 1.03125));
+        D3PM_TRY(layernorm_mx(dt, ws.x, x8, sx8, b.norm1_w, b.norm1_b, nullptr, nullptr, nullptr, nullptr, nullptr, n, d, 1e-6f, s));
+      }
+      D3PM_TRY(mx_gemm(x8, d, sx8, f8[l].attn_in_w8, f8[l].attn_in_scale, b.attn_in_b, ws.qkv, 3 * d, nullptr, nullptr, 1, nullptr, nullptr,
+                       n, 3 * d, d, ACT_NONE));
     } else {
       LnPrologue lp;
       lp.w = ln.w; lp.b = ln.b; lp.eps = ln.eps;
@@ -301,12 +317,14 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     char* q_text = ws.qkv;
     char* q_prom = at(ws.qkv, static_cast<size_t>(n) * d, es);
     if (use8) {
-      // e4m3 rows of norm2(x) | norm22(x) stacked [2n][d] (fills ws.h), scales [2n] at ws.h2: ONE fp8 GEMM for both queries
-      D3PM_TRY(layernorm_fp8(dt, ws.x, x8, sx8, b.norm2_w, b.norm2_b, nullptr, b.norm22_w, b.norm22_b,
-                             x8 + static_cast<size_t>(n) * d, sx8 + n, n, d, 1e-6f, s));
-      ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * 2 * n * d * d, 2.0 * n * d + 1.0 * d * d + es * 2.0 * n * d);
-      D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].cross_in_w8), f8[l].cross_in_scale, b.cross_in_b,
-                          q_text, d, 2 * n, d, d, ACT_NONE, s));
+      // MX rows of norm2(x) | norm22(x) stacked [2n][d] (fills ws.h), block scales [2n][16] at ws.h2: ONE GEMM for both queries
+      {
+        ProfScope p(cx, D3PM_K_LN, s, 0.0, static_cast<double>(n) * d * (es + 2 * 1.03125));
+        D3PM_TRY(layernorm_mx(dt, ws.x, x8, sx8, b.norm2_w, b.norm2_b, nullptr, b.norm22_w, b.norm22_b,
+                              x8 + static_cast<size_t>(n) * d, sx8 + static_cast<size_t>(n) * 16, n, d, 1e-6f, s));
+      }
+      D3PM_TRY(mx_gemm(x8, d, sx8, f8[l].cross_in_w8, f8[l].cross_in_scale, b.cross_in_b, q_text, d, nullptr, nullptr, 1, nullptr, nullptr,
+                       2 * n, d, d, ACT_NONE));
     } else if (ws.h2 == at(ws.h, static_cast<size_t>(n) * d, es)) {
       // both query projections share cross_attn's q rows: LN2|LN22 outputs and q_text|q_prompt are adjacent in
       // the workspace, so the pair is ONE [2n, d] x [d, d] GEMM (twice the workgroups of either alone)
@@ -365,11 +383,15 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     g = LinearArgs();
     g.X = ws.h; g.ldx = d; g.W = b.fc1_w; g.bias = b.fc1_b; g.Y = ws.mlp; g.ldy = 4 * d; g.M = n; g.N = 4 * d; g.K = d;
     g.act = ACT_GELU;
+    const bool fc2_mx = use8 && f8[l].fc2_w8 && f8[l].fc2_scale;
     if (use8) {
-      D3PM_TRY(layernorm_fp8(dt, ws.x, x8, sx8, b.norm3_w, b.norm3_b, ln.film, nullptr, nullptr, nullptr, nullptr, n, d, 1e-6f, s));
-      ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * g.M * g.N * g.K, 1.0 * g.M * g.K + 1.0 * g.N * g.K + es * g.M * g.N);
-      D3PM_TRY(fp8_linear(dt, x8, d, sx8, static_cast<const uint8_t*>(f8[l].fc1_w8), f8[l].fc1_scale, b.fc1_b, ws.mlp, 4 * d, n,
-                          4 * d, d, ACT_GELU, s));
+      {
+        ProfScope p(cx, D3PM_K_LN, s, 0.0, static_cast<double>(n) * d * (es + 1.03125));
+        D3PM_TRY(layernorm_mx(dt, ws.x, x8, sx8, b.norm3_w, b.norm3_b, ln.film, nullptr, nullptr, nullptr, nullptr, n, d, 1e-6f, s));
+      }
+      // with an MX fc2 the GELU epilogue writes the hidden layer as codes + block scales (half the bytes out, half in again)
+      D3PM_TRY(mx_gemm(x8, d, sx8, f8[l].fc1_w8, f8[l].fc1_scale, b.fc1_b, ws.mlp, 4 * d, nullptr, nullptr, 1, fc2_mx ? h8 : nullptr,
+                       fc2_mx ? sh8 : nullptr, n, 4 * d, d, ACT_GELU));
     } else {
       LnPrologue lp;
       lp.w = ln.w; lp.b = ln.b; lp.film = ln.film; lp.eps = ln.eps;
@@ -387,7 +409,10 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     g.row_mask = frame_mask; g.mask_period = T; g.M = n; g.N = d; g.K = 4 * d;
     rp = RowPanelFuse();
     if (l + 1 < layers) { rp.lnw = w.blocks[l + 1].norm1_w; rp.lnb = w.blocks[l + 1].norm1_b; rp.lny = ws.h; rp.eps = 1e-6f; }
-    if ((panel & 4) && l + 1 < layers && row_panel_supported(dt, g, rp)) {
+    if (fc2_mx) {
+      D3PM_TRY(mx_gemm(h8, 4 * d, sh8, f8[l].fc2_w8, f8[l].fc2_scale, b.fc2_b, ws.x, d, ws.x, frame_mask, T, nullptr, nullptr, n, d, 4 * d,
+                       ACT_NONE));
+    } else if ((panel & 4) && l + 1 < layers && row_panel_supported(dt, g, rp)) {
       D3PM_TRY(run_row_panel(cx, dt, g, rp, s));
       norm1_done = true;
     } else {
@@ -803,20 +828,29 @@ int d3pm_op_linear(int dtype, int family, const void* X, int ldx, const void* W,
   return run_linear(cx, dtype, g, 0, s);
 }
 
-int d3pm_op_linear_fp8(int out_dtype, const void* X8, int ldx, const float* sx, const void* W8, const float* sw, const void* bias,
-                       void* Y, int ldy, int M, int N, int K, int act, void* stream) {
-  D3PM_REQUIRE(X8 && sx && W8 && sw && Y && M > 0 && N > 0 && K > 0, D3PM_E_ARG, "d3pm_op_linear_fp8: bad arguments");
-  D3PM_REQUIRE(fp8_linear_supported(out_dtype, M, N, K, ldx, ldy), D3PM_E_SHAPE,
-               "d3pm_op_linear_fp8: needs M, N, K multiples of 128 and a 16-bit output type");
-  return fp8_linear(out_dtype, static_cast<const uint8_t*>(X8), ldx, sx, static_cast<const uint8_t*>(W8), sw, bias, Y, ldy, M, N,
-                    K, act, static_cast<hipStream_t>(stream));
+int d3pm_op_quantize_mx(int dtype, const void* X, int ldx, void* X8, void* SX, int M, int K, void* stream) {
+  D3PM_REQUIRE(X && X8 && SX && M > 0 && K > 0, D3PM_E_ARG, "d3pm_op_quantize_mx: bad arguments");
+  return quantize_mx(dtype, X, ldx, static_cast<uint8_t*>(X8), static_cast<uint8_t*>(SX), M, K, static_cast<hipStream_t>(stream));
 }
 
-int d3pm_op_layernorm_fp8(int dtype, const void* X, void* Y8, float* sx, const void* w, const void* b, const void* film, int M,
-                          int d, float eps, void* stream) {
-  D3PM_REQUIRE(X && Y8 && sx && w && b && M > 0, D3PM_E_ARG, "d3pm_op_layernorm_fp8: bad arguments");
-  return layernorm_fp8(dtype, X, static_cast<uint8_t*>(Y8), sx, w, b, film, nullptr, nullptr, nullptr, nullptr, M, d, eps,
-                       static_cast<hipStream_t>(stream));
+int d3pm_op_layernorm_mx(int dtype, const void* X, void* Y8, void* SX, const void* w, const void* b, const void* film, int M, int d,
+                         float eps, void* stream) {
+  D3PM_REQUIRE(X && Y8 && SX && w && b && M > 0, D3PM_E_ARG, "d3pm_op_layernorm_mx: bad arguments");
+  return layernorm_mx(dtype, X, static_cast<uint8_t*>(Y8), static_cast<uint8_t*>(SX), w, b, film, nullptr, nullptr, nullptr, nullptr, M, d,
+                      eps, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_op_linear_mx(int out_dtype, const void* X8, int ldx, const void* SX, const void* W8, const void* SW, const void* bias, void* Y,
+                      int ldy, const void* R1, int ldr, const uint8_t* row_mask, int mask_period, void* Y8, void* SY, int M, int N, int K,
+                      int act, void* stream) {
+  D3PM_REQUIRE(X8 && SX && W8 && SW && (Y || Y8) && M > 0 && N > 0 && K > 0, D3PM_E_ARG, "d3pm_op_linear_mx: bad arguments");
+  MxLinearArgs m;
+  m.X8 = X8; m.ldx = ldx; m.SX = SX; m.W8 = W8; m.SW = SW; m.bias = bias; m.Y = Y; m.ldy = ldy; m.R1 = R1; m.ldr = ldr;
+  m.row_mask = row_mask; m.mask_period = mask_period > 0 ? mask_period : 1; m.Y8 = Y8; m.SY = SY; m.M = M; m.N = N; m.K = K; m.act = act;
+  D3PM_REQUIRE(mx_linear_supported(out_dtype, m), D3PM_E_SHAPE,
+               "d3pm_op_linear_mx: needs M a multiple of 192, N of 128, K of 512, a 16-bit output type, 16-byte aligned operands and "
+               "one of the epilogues plain / GELU / R1 / R1 + mask (MX output: plain / GELU)");
+  return mx_linear(out_dtype, m, static_cast<hipStream_t>(stream));
 }
 
 int d3pm_op_attention(int dtype, int family, const void* Q, int ldq, const void* K, const void* V, int ldkv, void* O,

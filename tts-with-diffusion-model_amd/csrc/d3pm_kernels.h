@@ -125,12 +125,25 @@ int cond_embed_prompt(int dtype, const int32_t* codes, int n_levels, const void*
                       int rows, int s_prompt, int d, int n_classes, hipStream_t s);
 int posterior_sample(const SampleArgs& a, hipStream_t s);
 
-// fp8 (OCP e4m3) fast path for the LayerNorm-fed K = d_model projections (d3pm_fp8.hip)
-bool fp8_linear_supported(int out_dtype, int M, int N, int K, int ldx, int ldy);
-int fp8_linear(int out_dtype, const uint8_t* X, int ldx, const float* sx, const uint8_t* W, const float* sw, const void* bias,
-               void* Y, int ldy, int M, int N, int K, int act, hipStream_t s);
-int layernorm_fp8(int dtype, const void* x, uint8_t* y8, float* sx, const void* w, const void* b, const void* film,
-                  const void* w2, const void* b2, uint8_t* y8_2, float* sx_2, int M, int d, float eps, hipStream_t s);
+// fp8 fast path on the block-scaled MFMA (d3pm_mx.hip): e4m3 codes [rows][K] + e8m0 block scales [rows][4][K / 128]
+//   Y[M][N] = epilogue(sum_k X8 2^sx . W8 2^sw + bias), epilogue as LinearArgs (plain, GELU, R1, R1 + mask); with Y8 / SY set the
+//   output is written in the MX format itself (codes [M][N] + scales [M][4][N / 128]: the next projection's operand) instead of Y
+struct MxLinearArgs {
+  const void* X8 = nullptr; int ldx = 0; const void* SX = nullptr;
+  const void* W8 = nullptr; const void* SW = nullptr;
+  const void* bias = nullptr;
+  void* Y = nullptr; int ldy = 0;
+  const void* R1 = nullptr; int ldr = 0;
+  const uint8_t* row_mask = nullptr; int mask_period = 1;
+  void* Y8 = nullptr; void* SY = nullptr;
+  int M = 0, N = 0, K = 0;
+  int act = ACT_NONE;
+};
+bool mx_linear_supported(int dtype, const MxLinearArgs& a);
+int mx_linear(int dtype, const MxLinearArgs& a, hipStream_t s);
+int layernorm_mx(int dtype, const void* x, uint8_t* y8, uint8_t* sx, const void* w, const void* b, const void* film,
+                 const void* w2, const void* b2, uint8_t* y8_2, uint8_t* sx_2, int M, int d, float eps, hipStream_t s);
+int quantize_mx(int dtype, const void* x, int ldx, uint8_t* y8, uint8_t* sx, int M, int K, hipStream_t s);
 
 // MFMA family: return D3PM_E_SHAPE when the shape does not fit (caller falls back to generic)
 bool mfma_linear_supported(int dtype, const LinearArgs& a);

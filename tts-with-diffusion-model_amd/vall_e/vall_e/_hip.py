@@ -124,10 +124,12 @@ SIGNATURES = {
     "d3pm_sample_loop_fp8": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ScheduleC),
                                        C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
-    "d3pm_op_linear_fp8": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "d3pm_op_layernorm_fp8": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "d3pm_op_quantize_mx": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "d3pm_op_layernorm_mx": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "d3pm_op_linear_mx": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p]),
     "d3pm_ce_loss_rows": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "d3pm_uniform": (C.c_int, [C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -295,20 +297,24 @@ class DeviceWeights:
 
 class Fp8BlockWeights(C.Structure):
     _fields_ = [("attn_in_w8", C.c_void_p), ("attn_in_scale", C.c_void_p), ("cross_in_w8", C.c_void_p),
-                ("cross_in_scale", C.c_void_p), ("fc1_w8", C.c_void_p), ("fc1_scale", C.c_void_p)]
+                ("cross_in_scale", C.c_void_p), ("fc1_w8", C.c_void_p), ("fc1_scale", C.c_void_p),
+                ("fc2_w8", C.c_void_p), ("fc2_scale", C.c_void_p)]
 
 
 class DeviceFp8Weights:
-    """e4m3 copies (per output channel scales) of the LayerNorm-fed projections of every block for the fp8 fast path."""
+    """Block-scaled e4m3 copies (quantize_mx) of the LayerNorm-fed projections -- and of fc2 unless `fc2=False` -- of every
+    block for the fp8 fast path."""
 
-    def __init__(self, tensors: dict, n_layers: int, d_model: int):
+    def __init__(self, tensors: dict, n_layers: int, d_model: int, fc2: bool = True):
         self._keep = []
         self.blocks = (Fp8BlockWeights * n_layers)()
+        which = [("attn_in", "attn.in_proj_weight", None), ("cross_in", "cross_attn.in_proj_weight", d_model), ("fc1", "mlp.fc1.weight", None)]
+        if fc2:
+            which.append(("fc2", "mlp.fc2.weight", None))
         for i in range(n_layers):
-            for field, key, rows in (("attn_in", "attn.in_proj_weight", None), ("cross_in", "cross_attn.in_proj_weight", d_model),
-                                     ("fc1", "mlp.fc1.weight", None)):
+            for field, key, rows in which:
                 w = tensors[f"blocks.{i}.{key}"]
-                codes, scale = quantize_rows_e4m3(w[:rows] if rows else w)
+                codes, scale = quantize_mx(w[:rows] if rows else w)
                 self._keep += [codes, scale]
                 setattr(self.blocks[i], field + "_w8", codes.data_ptr())
                 setattr(self.blocks[i], field + "_scale", scale.data_ptr())
@@ -375,6 +381,7 @@ class Sampler:
         self.shape = make_shape(cfg, dtype)
         self.weights = DeviceWeights(tensors, cfg.n_layers)
         self._tensors, self._fp8 = tensors, None
+        self.fp8_fc2 = True        # the fp8 fast path also runs fc2 on MX operands (fc1 writes the hidden layer in that format)
         self.cond_weights = (DeviceCondWeights(tensors, cfg, pe_text0, pe_prompt)
                              if pe_text0 is not None and "encodertext.1.fc1.weight" in tensors else None)
         self._cond_ws = None
@@ -390,7 +397,7 @@ class Sampler:
         if self._fp8 is None:
             if self.cfg.d_model != 512 or self.dtype == torch.float32:
                 raise D3PMError("the fp8 fast path needs d_model = 512 and a 16-bit model dtype")
-            self._fp8 = DeviceFp8Weights(self._tensors, self.cfg.n_layers, self.cfg.d_model)
+            self._fp8 = DeviceFp8Weights(self._tensors, self.cfg.n_layers, self.cfg.d_model, fc2=self.fp8_fc2)
         return self._fp8
 
     def workspace(self, batch: int, slot: int = 0) -> torch.Tensor:
@@ -598,31 +605,66 @@ def op_linear(x, w, bias=None, *, act=0, r1=None, r2=None, row_mask=None, mask_p
     return y[:, :N]
 
 
-def quantize_rows_e4m3(w: torch.Tensor):
-    """[N, K] -> (uint8 e4m3 codes [N, K], fp32 scale [N]) with scale = absmax_row / 448 (the weight side of the fp8
-    path: per output channel; torch's float8_e4m3fn is the OCP format gfx950 computes in)."""
-    wf = w.float()
-    scale = wf.abs().amax(dim=1).clamp_min(1e-30) / 448.0
-    codes = (wf / scale[:, None]).to(torch.float8_e4m3fn)
-    return codes.view(torch.uint8).contiguous(), scale.contiguous()
+def mx_scale_bytes(amax: torch.Tensor) -> torch.Tensor:
+    """e8m0 byte of a block's absolute maximum (csrc/d3pm_mx.hip: mx_scale_byte): the smallest power of two 2^(byte - 127)
+    with amax / scale <= 448, exact integer arithmetic on the fp32 bits."""
+    bits = amax.float().contiguous().view(torch.int32)
+    e = (bits >> 23) - 8 + ((bits & 0x7FFFFF) > 0x600000).to(torch.int32)
+    return e.clamp(1, 254).to(torch.uint8)
 
 
-def op_layernorm_fp8(x, w, b, film=None, eps=1e-6):
+def quantize_mx(w: torch.Tensor):
+    """[N, K] (K a multiple of 128) -> (uint8 e4m3 codes [N, K], uint8 e8m0 scales [N, 4, K // 128]); blocks of 32 along K.
+    The weight side of the fp8 path (host / torch arithmetic; torch's float8_e4m3fn is the OCP format gfx950 computes in); the
+    device-side quantisers (d3pm_op_quantize_mx, d3pm_op_layernorm_mx, the MX epilogue) apply the same rule."""
+    N, K = w.shape
+    assert K % 128 == 0
+    wf = w.float().reshape(N, K // 128, 4, 32)
+    sb = mx_scale_bytes(wf.abs().amax(dim=-1))                       # [N, K/128, 4]
+    inv = torch.exp2(127.0 - sb.float())
+    codes = (wf * inv[..., None]).to(torch.float8_e4m3fn).view(torch.uint8).reshape(N, K)
+    return codes.contiguous(), sb.permute(0, 2, 1).contiguous()
+
+
+def dequantize_mx(codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """fp32 values of an MX tensor (codes [N, K], scales [N, 4, K // 128]): exact."""
+    N, K = codes.shape
+    sc = torch.exp2(scales.permute(0, 2, 1).float() - 127.0)        # [N, K/128, 4]
+    return (codes.view(torch.float8_e4m3fn).float().reshape(N, K // 128, 4, 32) * sc[..., None]).reshape(N, K)
+
+
+def op_quantize_mx(x):
+    M, K = x.shape
+    x8 = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    sx = torch.empty((M, 4, K // 128), dtype=torch.uint8, device=x.device)
+    check(lib().d3pm_op_quantize_mx(dtype_code(x.dtype), _p(x), x.stride(0), _p(x8), _p(sx), M, K, stream_ptr()), "d3pm_op_quantize_mx")
+    return x8, sx
+
+
+def op_layernorm_mx(x, w, b, film=None, eps=1e-6):
     M, d = x.shape
     y8 = torch.empty((M, d), dtype=torch.uint8, device=x.device)
-    sx = torch.empty(M, dtype=torch.float32, device=x.device)
-    check(lib().d3pm_op_layernorm_fp8(dtype_code(x.dtype), _p(x), _p(y8), _p(sx), _p(w), _p(b), _p(film), M, d, eps,
-                                      stream_ptr()), "d3pm_op_layernorm_fp8")
+    sx = torch.empty((M, 4, d // 128), dtype=torch.uint8, device=x.device)
+    check(lib().d3pm_op_layernorm_mx(dtype_code(x.dtype), _p(x), _p(y8), _p(sx), _p(w), _p(b), _p(film), M, d, eps,
+                                     stream_ptr()), "d3pm_op_layernorm_mx")
     return y8, sx
 
 
-def op_linear_fp8(x8, sx, w8, sw, bias, out_dtype, *, act=0):
+def op_linear_mx(x8, sx, w8, sw, bias, out_dtype, *, act=0, r1=None, row_mask=None, mask_period=1, mx_out=False):
+    """16-bit result [M, N], or with mx_out=True the result as (codes [M, N], scales [M, 4, N // 128])."""
     M, K = x8.shape
     N = w8.shape[0]
-    y = torch.empty((M, N), dtype=out_dtype, device=x8.device)
-    check(lib().d3pm_op_linear_fp8(dtype_code(out_dtype), _p(x8), x8.stride(0), _p(sx), _p(w8), _p(sw), _p(bias), _p(y), N,
-                                   M, N, K, act, stream_ptr()), "d3pm_op_linear_fp8")
-    return y
+    if mx_out:
+        y8 = torch.empty((M, N), dtype=torch.uint8, device=x8.device)
+        sy = torch.empty((M, 4, N // 128), dtype=torch.uint8, device=x8.device)
+        y = None
+    else:
+        y8 = sy = None
+        y = torch.empty((M, N), dtype=out_dtype, device=x8.device)
+    check(lib().d3pm_op_linear_mx(dtype_code(out_dtype), _p(x8), x8.stride(0), _p(sx), _p(w8), _p(sw), _p(bias), _p(y), N, _p(r1),
+                                  0 if r1 is None else r1.stride(0), _p(row_mask), mask_period, _p(y8), _p(sy), M, N, K, act,
+                                  stream_ptr()), "d3pm_op_linear_mx")
+    return (y8, sy) if mx_out else y
 
 
 def op_attention(q, k, v, n_heads, scale, *, family=0):

@@ -261,9 +261,9 @@ class AR(SymmapState, nn.Module):
         """Reverse diffusion for len(text_list) utterances.  Positional behaviour as upstream:
         one utterance -> int64 [canvas] (squeezed, untrimmed; rows >= n_frames are sampled from
         final.bias and meaningless).  `resps_list` is ignored, as upstream ignores it (:699).
-        `fp8=True` is the fast configuration of BASELINE.json configs[4]: the QKV, cross-attention query and fc1
-        projections take e4m3 operands (d_model = 512, 16-bit model, batch * canvas a multiple of 128); the reference
-        has no such mode.
+        `fp8=True` is the fast configuration of BASELINE.json configs[4]: the QKV, cross-attention query, fc1 and fc2
+        projections run on the block-scaled fp8 matrix instruction (e4m3 codes, one power-of-two scale per 32 elements;
+        d_model = 512, 16-bit model, batch * canvas a multiple of 192); the reference has no such mode.
         `graph=True` replays the loop from a captured HIP graph (seed read from HBM, identical results).  Off by
         default: measured on MI355X one utterance takes 66.6 ms replayed and 66.3 ms launched eagerly -- the ~5000
         kernels of a reverse process are bound by their own ~10 us latency at M = 768 rows, not by launch overhead."""
