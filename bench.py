@@ -176,7 +176,7 @@ def fp8_fast_path(dev, dtype, batch, cfg, sd32, texts, proms):
     out["speedup_fp8_vs_bf16_same_schedule"] = out["fp8_50_steps"]["codec_tokens_per_s"] / out["bf16_50_steps"]["codec_tokens_per_s"]
     out["note"] = ("49 iterations (timesteps = 50), same synthetic weights except time_emb (random init for the shorter "
                    "schedule); fp8 = block-scaled e4m3 (v_mfma_scale_f32_16x16x128_f8f6f4, one power-of-two scale per 32 elements) "
-                   "for norm1->QKV, norm2|22->cross q, norm3->fc1 (GELU epilogue writes the hidden layer in that format) and fc2; "
+                   "for norm1->QKV, norm2|22->cross q, norm3->fc1; the LayerNorm rows leave the row-panel out-projections in that format; "
                    "free-running id agreement compounds single near-tie flips over 49 iterations (teacher-forced agreement and "
                    "logits error: tests/test_gpu_parity.py::test_fp8_fast_path_agreement_with_the_16_bit_path)")
     return out

@@ -360,13 +360,13 @@ int d3pm_op_linear(int dtype, int family, const void *X, int ldx, const void *W,
  *   linear_mx:     epilogue(sum_k X8 2^sx . W8 2^sw + bias) with fp32 accumulation: act 0 none / 1 GELU, optional residual
  *                  R1 [M][N] and row mask as d3pm_op_linear, 16-bit output Y [M][ldy] in `out_dtype` -- or, with Y8 / SY given
  *                  (R1 = row_mask = NULL, Y ignored), the output itself in the MX format: Y8 [M][N], SY [M][4][N / 128].
- *                  M a multiple of 192, N of 128, K of 512. */
+ *                  M a multiple of 192, N of 128, K of 512.  tuning->gemm_variant 6 / 8 pins the 192 x 256 / 192 x 128 tile. */
 int d3pm_op_quantize_mx(int dtype, const void *X, int ldx, void *X8, void *SX, int M, int K, void *stream);
 int d3pm_op_layernorm_mx(int dtype, const void *X, void *Y8, void *SX, const void *w, const void *b, const void *film, int M,
                          int d, float eps, void *stream);
 int d3pm_op_linear_mx(int out_dtype, const void *X8, int ldx, const void *SX, const void *W8, const void *SW, const void *bias,
                       void *Y, int ldy, const void *R1, int ldr, const uint8_t *row_mask, int mask_period, void *Y8, void *SY,
-                      int M, int N, int K, int act, void *stream);
+                      int M, int N, int K, int act, const d3pm_tuning *tuning, void *stream);
 int d3pm_op_attention(int dtype, int family, const void *Q, int ldq, const void *K, const void *V, int ldkv,
                       void *O, int ldo, int B, int Tq, int S, int H, int hd, float scale, const d3pm_tuning *tuning,
                       void *stream);
@@ -382,11 +382,13 @@ int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const vo
  *   MLP down-projection (:159-161): row_mask given, X2 = film = ln2_* = NULL:
  *       Y = rn(R1 + rn(X W^T + bias)) * mask[row % mask_period],  ln_y = norm1 of the NEXT block (:131).
  * X (and X2) [M][ldx], W [512][K], Y / R1 / ln_y / ln2_y [M][512] (Y may alias R1), M a multiple of 96, K a multiple of 128.
- * D3PM_E_SHAPE for any other combination. */
+ * fp8 fast path: with ln_sx (and ln2_sx) given -- first two forms only -- the LayerNorm rows leave in the block-scaled fp8
+ * format (d3pm_op_quantize_mx of the 16-bit LayerNorm result, bit for bit): ln_y / ln2_y are then code buffers [M][512] bytes
+ * and ln_sx / ln2_sx receive the scales [M][4][4].  D3PM_E_SHAPE for any other combination. */
 int d3pm_op_linear_rowpanel(int dtype, const void *X, const void *X2, int ldx, const void *W, const void *bias, void *Y,
                             const void *R1, const uint8_t *row_mask, int mask_period, int M, int K, const void *ln_w,
                             const void *ln_b, void *ln_y, const void *ln2_w, const void *ln2_b, void *ln2_y,
-                            const void *film, float eps, void *stream);
+                            const void *film, float eps, void *ln_sx, void *ln2_sx, void *stream);
 
 /* Timing hooks for bench.py's roofline object.  A d3pm_prof attached to a tuning (d3pm_tuning.prof) makes every launch of the
  * kernel class `kclass` (D3PM_K_*; D3PM_K_COUNT = every class) made INSIDE d3pm_sample_loop with that tuning be bracketed by a

@@ -419,6 +419,15 @@ def test_row_panel_projection_equals_linear_then_layernorm(built_lib, dtype, for
     assert torch.equal(y, y_ref), f"{form}: residual stream differs in {(y != y_ref).sum().item()} elements"
     for i, (o, r) in enumerate(zip(outs, refs)):
         assert torch.equal(o, r), f"{form}: LayerNorm output {i} differs in {(o != r).sum().item()} elements"
+    if form != "mlp_down":
+        # fp8 fast path: the same launch with its LayerNorm rows leaving as MX codes + block scales = the block rule applied
+        # to the 16-bit LayerNorm result, bit for bit (torch-side rule: _hip.quantize_mx)
+        kw = dict(ln2_w=lw2, ln2_b=lb2) if form == "self_out" else dict(x2=x2, film=film)
+        y8, m1, m2 = _hip.op_linear_rowpanel(x, w, b, r1, lw, lb, mx=True, **kw)
+        assert torch.equal(y8, y_ref)
+        for (codes, scales), r in zip([m for m in (m1, m2) if m is not None], refs):
+            rc, rs = _hip.quantize_mx(r)
+            assert torch.equal(scales, rs) and torch.equal(codes, rc), f"{form}: MX LayerNorm rows differ"
 
 
 def test_row_panel_rejects_other_combinations(built_lib):

@@ -219,17 +219,19 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     D3PM_REQUIRE(d == 512 && (dt == D3PM_F16 || dt == D3PM_BF16) && n % 192 == 0 && ws.h2 == at(ws.h, static_cast<size_t>(n) * d, dtype_size(dt)),
                  D3PM_E_SHAPE, "fp8 fast path needs d_model = 512, a 16-bit model dtype and batch * canvas (%d) a multiple of 192", n);
   }
-  // MX operands of the LayerNorm-fed projections live where the 16-bit LayerNorm outputs would: codes [2n][512] fill ws.h,
-  // their block scales [2n][16] start at ws.h2; fc1's MX output (codes [n][2048] + scales [n][64]) lives in ws.mlp
+  // MX operands of the LayerNorm-fed projections live where the 16-bit LayerNorm outputs would: codes [2n][512] fill ws.h.
+  // The shared qkv | q | hidden | logits region (n x 4d elements = 4096 n bytes) also holds: fc1's MX output, codes [n][2048] at
+  // its start and scales [n][64] at byte 2048 n; the LayerNorm block scales [2n][16] at byte 3072 n -- beyond everything that is
+  // written there while they are read (packed qkv rows end at 3072 n, the queries at 2048 n, the hidden layer at 2112 n)
   uint8_t* x8 = reinterpret_cast<uint8_t*>(ws.h);
-  uint8_t* sx8 = reinterpret_cast<uint8_t*>(ws.h2);
   uint8_t* h8 = reinterpret_cast<uint8_t*>(ws.mlp);
   uint8_t* sh8 = h8 + static_cast<size_t>(n) * 4 * d;
+  uint8_t* sx8 = h8 + static_cast<size_t>(n) * 6 * d;
   auto mx_gemm = [&](const uint8_t* X8, int ldx8, const uint8_t* SX8, const void* W8, const void* SW8, const void* bias, void* Y, int ldy,
                      const void* R1, const uint8_t* mask, int period, uint8_t* Y8, uint8_t* SY, int M, int N, int K, int act) -> int {
     MxLinearArgs m;
     m.X8 = X8; m.ldx = ldx8; m.SX = SX8; m.W8 = W8; m.SW = SW8; m.bias = bias; m.Y = Y; m.ldy = ldy; m.R1 = R1; m.ldr = ldy;
-    m.row_mask = mask; m.mask_period = period; m.Y8 = Y8; m.SY = SY; m.M = M; m.N = N; m.K = K; m.act = act;
+    m.row_mask = mask; m.mask_period = period; m.Y8 = Y8; m.SY = SY; m.M = M; m.N = N; m.K = K; m.act = act; m.tune = cx.tune;
     D3PM_REQUIRE(mx_linear_supported(dt, m), D3PM_E_SHAPE, "fp8 fast path: block-scaled GEMM %d x %d x %d not supported", M, N, K);
     ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * M * N * K,
                 1.03125 * (static_cast<double>(M) * K + static_cast<double>(N) * K) + static_cast<double>(M) * N * (Y8 ? 1.03125 : (R1 ? 2.0 : 1.0) * es));
@@ -260,7 +262,8 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
   // (one 96-row tile per workgroup: only when the tiles fill >= 85 % of whole rounds over the 256 CUs, as for the other big tiles)
   const long long rp_tiles = n / 96, rp_rounds = (rp_tiles + 255) / 256;
   const bool rp_fills = n % 96 == 0 && rp_tiles * 5 >= 256 * 4 && rp_tiles * 100 >= rp_rounds * 256 * 85;
-  const int panel = (!use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && rp_fills && (dt == D3PM_F16 || dt == D3PM_BF16)) ? (tune_of(sh.tuning).row_panel & 7) : 0;
+  const int panel = (!(flags & D3PM_FLAG_FORCE_GENERIC) && d == 512 && rp_fills && (dt == D3PM_F16 || dt == D3PM_BF16))
+                        ? (tune_of(sh.tuning).row_panel & (use8 ? 3 : 7)) : 0;      // fp8: fc2 is a block-scaled GEMM of its own
   bool norm1_done = embed_fused;   // norm1(x) of this block is already in ws.h (the embedding launch, or the previous block's fc2)
   // the opposite regime (one or two utterances, latency GEMM): LayerNorm runs as the prologue of the projection it feeds
 #ifdef D3PM_ABLATIONS
@@ -311,14 +314,17 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     ln.M = n; ln.d = d; ln.eps = 1e-6f;
     RowPanelFuse rp;
     rp.lnw = ln.w; rp.lnb = ln.b; rp.lny = ln.Y; rp.lnw2 = ln.w2; rp.lnb2 = ln.b2; rp.lny2 = ln.Y2; rp.eps = ln.eps;
+    if (use8) {      // the LayerNorm rows leave the row-panel launch as MX codes + block scales: the query projection's operand
+      rp.lny = x8; rp.lny2 = x8 + static_cast<size_t>(n) * d; rp.sx = sx8; rp.sx2 = sx8 + static_cast<size_t>(n) * 16;
+    }
     const bool norm2_fused = (panel & 1) && row_panel_supported(dt, g, rp);
     if (norm2_fused) D3PM_TRY(run_row_panel(cx, dt, g, rp, s));
     else D3PM_TRY(run_linear(cx, dt, g, flags, s));
     char* q_text = ws.qkv;
     char* q_prom = at(ws.qkv, static_cast<size_t>(n) * d, es);
     if (use8) {
-      // MX rows of norm2(x) | norm22(x) stacked [2n][d] (fills ws.h), block scales [2n][16] at ws.h2: ONE GEMM for both queries
-      {
+      // MX rows of norm2(x) | norm22(x) stacked [2n][d] (fills ws.h), block scales [2n][16]: ONE GEMM for both queries
+      if (!norm2_fused) {
         ProfScope p(cx, D3PM_K_LN, s, 0.0, static_cast<double>(n) * d * (es + 2 * 1.03125));
         D3PM_TRY(layernorm_mx(dt, ws.x, x8, sx8, b.norm2_w, b.norm2_b, nullptr, b.norm22_w, b.norm22_b,
                               x8 + static_cast<size_t>(n) * d, sx8 + static_cast<size_t>(n) * 16, n, d, 1e-6f, s));
@@ -367,6 +373,7 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     g.M = n; g.N = d; g.K = d;
     rp = RowPanelFuse();
     rp.X2 = ws.att2; rp.lnw = ln.w; rp.lnb = ln.b; rp.lny = ln.Y; rp.film = ln.film; rp.eps = ln.eps;
+    if (use8) { rp.lny = x8; rp.sx = sx8; }
     const bool norm3_fused = (panel & 2) && row_panel_supported(dt, g, rp);
     if (norm3_fused) {
       D3PM_TRY(run_row_panel(cx, dt, g, rp, s));
@@ -385,7 +392,7 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     g.act = ACT_GELU;
     const bool fc2_mx = use8 && f8[l].fc2_w8 && f8[l].fc2_scale;
     if (use8) {
-      {
+      if (!norm3_fused) {
         ProfScope p(cx, D3PM_K_LN, s, 0.0, static_cast<double>(n) * d * (es + 1.03125));
         D3PM_TRY(layernorm_mx(dt, ws.x, x8, sx8, b.norm3_w, b.norm3_b, ln.film, nullptr, nullptr, nullptr, nullptr, n, d, 1e-6f, s));
       }
@@ -842,11 +849,12 @@ int d3pm_op_layernorm_mx(int dtype, const void* X, void* Y8, void* SX, const voi
 
 int d3pm_op_linear_mx(int out_dtype, const void* X8, int ldx, const void* SX, const void* W8, const void* SW, const void* bias, void* Y,
                       int ldy, const void* R1, int ldr, const uint8_t* row_mask, int mask_period, void* Y8, void* SY, int M, int N, int K,
-                      int act, void* stream) {
+                      int act, const d3pm_tuning* tuning, void* stream) {
   D3PM_REQUIRE(X8 && SX && W8 && SW && (Y || Y8) && M > 0 && N > 0 && K > 0, D3PM_E_ARG, "d3pm_op_linear_mx: bad arguments");
   MxLinearArgs m;
   m.X8 = X8; m.ldx = ldx; m.SX = SX; m.W8 = W8; m.SW = SW; m.bias = bias; m.Y = Y; m.ldy = ldy; m.R1 = R1; m.ldr = ldr;
   m.row_mask = row_mask; m.mask_period = mask_period > 0 ? mask_period : 1; m.Y8 = Y8; m.SY = SY; m.M = M; m.N = N; m.K = K; m.act = act;
+  m.tune = tuning;
   D3PM_REQUIRE(mx_linear_supported(out_dtype, m), D3PM_E_SHAPE,
                "d3pm_op_linear_mx: needs M a multiple of 192, N of 128, K of 512, a 16-bit output type, 16-byte aligned operands and "
                "one of the epilogues plain / GELU / R1 / R1 + mask (MX output: plain / GELU)");
@@ -897,13 +905,15 @@ int d3pm_op_linear_lnpro(int dtype, const void* X, const void* W, const void* bi
 
 int d3pm_op_linear_rowpanel(int dtype, const void* X, const void* X2, int ldx, const void* W, const void* bias, void* Y, const void* R1,
                             const uint8_t* row_mask, int mask_period, int M, int K, const void* ln_w, const void* ln_b, void* ln_y,
-                            const void* ln2_w, const void* ln2_b, void* ln2_y, const void* film, float eps, void* stream) {
+                            const void* ln2_w, const void* ln2_b, void* ln2_y, const void* film, float eps, void* ln_sx, void* ln2_sx,
+                            void* stream) {
   D3PM_REQUIRE(X && W && bias && Y && R1 && ln_w && ln_b && ln_y && M > 0 && K > 0, D3PM_E_ARG, "d3pm_op_linear_rowpanel: bad arguments");
   LinearArgs g;
   g.X = X; g.ldx = ldx; g.W = W; g.bias = bias; g.Y = Y; g.ldy = 512; g.R1 = R1; g.ldr = 512; g.row_mask = row_mask;
   g.mask_period = mask_period > 0 ? mask_period : 1; g.M = M; g.N = 512; g.K = K;
   RowPanelFuse f;
   f.X2 = X2; f.lnw = ln_w; f.lnb = ln_b; f.lny = ln_y; f.lnw2 = ln2_w; f.lnb2 = ln2_b; f.lny2 = ln2_y; f.film = film; f.eps = eps;
+  f.sx = ln_sx; f.sx2 = ln2_sx;
   D3PM_REQUIRE(row_panel_supported(dtype, g, f), D3PM_E_SHAPE,
                "d3pm_op_linear_rowpanel: needs a 16-bit dtype, M a multiple of 96, K a multiple of 128 (>= 256), 16-byte aligned "
                "operands and one of the three fused forms (include/d3pm_hip.h)");

@@ -79,6 +79,9 @@ struct RowPanelFuse {
   const void* lnw2 = nullptr; const void* lnb2 = nullptr; void* lny2 = nullptr;     // a second LayerNorm of the same rows
   const void* film = nullptr;                                // FiLM (scale | shift, 2 x 512) on the first
   float eps = 1e-6f;
+  // fp8 fast path: with sx (and sx2) set, lny (lny2) receive the LayerNorm rows in the block-scaled fp8 format of d3pm_mx.hip --
+  // codes [M][512] bytes -- and sx (sx2) their scales [M][4][4]
+  void* sx = nullptr; void* sx2 = nullptr;
 };
 
 // LayerNorm applied to the operand rows inside the latency GEMM (d3pm_mfma_gemm_lat.hip): X is then the residual stream.
@@ -138,6 +141,7 @@ struct MxLinearArgs {
   void* Y8 = nullptr; void* SY = nullptr;
   int M = 0, N = 0, K = 0;
   int act = ACT_NONE;
+  const d3pm_tuning* tune = nullptr;
 };
 bool mx_linear_supported(int dtype, const MxLinearArgs& a);
 int mx_linear(int dtype, const MxLinearArgs& a, hipStream_t s);

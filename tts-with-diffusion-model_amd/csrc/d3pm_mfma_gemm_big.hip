@@ -23,6 +23,7 @@
 //     128 x 128 kernels (d3pm_mfma_tile.h): the accumulation order over k is identical, results are bit-identical.
 #include "d3pm_kernels.h"
 #include "d3pm_mfma_tile.h"
+#include "d3pm_mx.h"
 
 namespace d3pm {
 namespace {
@@ -69,11 +70,15 @@ __device__ unsigned long long g_big_stamp[4];   // MODE bit 8: {shader clocks, 1
 //   bit 1  LayerNorm of the finished rows (the NEXT op of the block, ar_discrete.py:131,136,153) in the epilogue: the row
 //          moments are reduced in registers, across lanes and across the eight waves (LDS) in the exact order of
 //          layernorm_vec (wave_sum_up), so the output is bit-identical to the stand-alone LayerNorm launch it replaces;
-//   bit 2  a second LayerNorm of the same rows (norm2 | norm22);   bit 3  FiLM on the first (norm3, :145-156).
+//   bit 2  a second LayerNorm of the same rows (norm2 | norm22);   bit 3  FiLM on the first (norm3, :145-156);
+//   bit 5  (fp8 fast path) the LayerNorm outputs leave in the block-scaled fp8 format of d3pm_mx.hip instead of 16 bit: lny / lny2
+//          are then code buffers [M][512] bytes and sx / sx2 their block scales [M][4][4]; the value that is quantised is the 16-bit
+//          LayerNorm result bit for bit (the four lanes that own 32 consecutive columns of a row own one MX block).
 template <typename T> struct RowPanelArgs {
   const T* X2; const T* lnw; const T* lnb; const T* lnw2; const T* lnb2; const T* film; T* lny; T* lny2; float eps;
+  uint8_t* sx; uint8_t* sx2;
 };
-constexpr int FUSE_DUAL = 1, FUSE_LN = 2, FUSE_LN2 = 4, FUSE_FILM = 8, FUSE_ABL_NOLN = 16;   // 16: timing-only (LayerNorm arithmetic skipped)
+constexpr int FUSE_DUAL = 1, FUSE_LN = 2, FUSE_LN2 = 4, FUSE_FILM = 8, FUSE_ABL_NOLN = 16, FUSE_MX = 32;   // 16: timing-only (LayerNorm arithmetic skipped)
 
 template <typename T, int EPI, int WM, int WN, int MODE, int FUSE = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __restrict__ X, int ldx, const T* __restrict__ W,
@@ -94,6 +99,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   constexpr bool kNoSync = (MODE & 64) != 0, kNoReads = (MODE & 128) != 0, kStamp = (MODE & 256) != 0;
   constexpr bool kPrioYoung = (MODE & 2) != 0, kPrioMfma = (MODE & 4) != 0, kDrip = (MODE & 8) != 0;
   constexpr bool kDual = (FUSE & FUSE_DUAL) != 0, kLn = (FUSE & FUSE_LN) != 0, kLn2 = (FUSE & FUSE_LN2) != 0, kFilm = (FUSE & FUSE_FILM) != 0;
+  constexpr bool kMx = (FUSE & FUSE_MX) != 0;
+  static_assert(!kMx || kLn, "the MX output is the LayerNorm output");
   static_assert(FUSE == 0 || (WM == 1 && WN == 8 && !kDrip && (MODE & 1)), "row-panel fusion: 96 x 512 tiles, hand-placed schedule");
   static_assert(!kLn2 || kLn, "the second LayerNorm shares the moments of the first");
   static_assert(!kDrip || kHand, "deferred stores ride in the hand-placed schedule");
@@ -423,6 +430,49 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
         row_total(part, 1, rstd);
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt) rstd[mt] = rsqrtf(rstd[mt] / 512.0f + rp.eps);
+        if constexpr (kMx) {
+          // the LayerNorm result(s) as MX rows: per row block both 32-column halves are finished, quantised and stored together
+          Pack8<T> wv[2], bv[2], sc[2], sh[2], w2v[2], b2v[2];
+#pragma unroll
+          for (int np = 0; np < 2; ++np) {
+            const int col = n0 + wn * 64 + np * 32 + nq;
+            wv[np] = *reinterpret_cast<const Pack8<T>*>(rp.lnw + col); bv[np] = *reinterpret_cast<const Pack8<T>*>(rp.lnb + col);
+            if constexpr (kFilm) { sc[np] = *reinterpret_cast<const Pack8<T>*>(rp.film + col); sh[np] = *reinterpret_cast<const Pack8<T>*>(rp.film + 512 + col); }
+            if constexpr (kLn2) { w2v[np] = *reinterpret_cast<const Pack8<T>*>(rp.lnw2 + col); b2v[np] = *reinterpret_cast<const Pack8<T>*>(rp.lnb2 + col); }
+          }
+          uint8_t* const y8 = reinterpret_cast<uint8_t*>(rp.lny);
+          uint8_t* const y8b = reinterpret_cast<uint8_t*>(rp.lny2);
+          const int col0 = n0 + wn * 64, blk = (col0 >> 5) + (lane >> 4);          // the block whose scale byte lanes g = 0 / 1 write
+#pragma unroll
+          for (int mt = 0; mt < 6; ++mt) {
+            uint2 cd[2], cd2[2];
+            uint32_t sb[2], sb2[2];
+#pragma unroll
+            for (int np = 0; np < 2; ++np) {
+              float v[8], o[8], o2[8];
+              unpack(mt * 2 + np, v);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const float nrm = (v[i] - mean[mt]) * rstd[mt];
+                o[i] = rn<T>(nrm * static_cast<float>(wv[np].v[i]) + static_cast<float>(bv[np].v[i]));
+                if constexpr (kFilm) {
+                  const float gg = rn<T>(1.0f + static_cast<float>(sc[np].v[i]));
+                  o[i] = rn<T>(rn<T>(o[i] * gg) + static_cast<float>(sh[np].v[i]));
+                }
+                if constexpr (kLn2) o2[i] = rn<T>(nrm * static_cast<float>(w2v[np].v[i]) + static_cast<float>(b2v[np].v[i]));
+              }
+              cd[np] = mx_block_quantise(o, sb[np]);
+              if constexpr (kLn2) cd2[np] = mx_block_quantise(o2, sb2[np]);
+            }
+            const size_t row = static_cast<size_t>(m0 + mt * 16 + (lane & 15));
+            mx_store_row64(cd[0], cd[1], y8 + row * 512 + col0, lane);
+            if constexpr (kLn2) mx_store_row64(cd2[0], cd2[1], y8b + row * 512 + col0, lane);
+            if (lane < 32) {
+              rp.sx[row * 16 + (blk & 3) * 4 + (blk >> 2)] = static_cast<uint8_t>(lane < 16 ? sb[0] : sb[1]);
+              if constexpr (kLn2) rp.sx2[row * 16 + (blk & 3) * 4 + (blk >> 2)] = static_cast<uint8_t>(lane < 16 ? sb2[0] : sb2[1]);
+            }
+          }
+        } else {
 #pragma unroll
         for (int np = 0; np < 2; ++np) {
           const int col = n0 + wn * 64 + np * 32 + nq;
@@ -457,6 +507,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
             }
           }
         }
+        }   // 16-bit LayerNorm outputs
       }
     } else if (kDrip && more) {      // keep the finished tile in registers: its stores go out inside the next tile's first k-steps
       epilogue_store<T, EPI, 4, 6, true, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
@@ -660,11 +711,14 @@ bool row_panel_supported(int dtype, const LinearArgs& a, const RowPanelFuse& f) 
   for (const void* p : {a.X, a.W, static_cast<const void*>(a.Y), a.R1, a.bias, f.X2, f.lnw, f.lnb, f.lnw2, f.lnb2, f.film,
                         static_cast<const void*>(f.lny), static_cast<const void*>(f.lny2)})
     if (!aligned16(p)) return false;
+  if ((f.sx != nullptr) != (f.sx2 != nullptr) && f.lnw2) return false;     // both LayerNorm outputs in the same format
+  if (f.sx && row_panel_kind(a, f) == 3) return false;                       // MX outputs: the two forms the fp8 fast path uses
   return row_panel_kind(a, f) != 0;
 }
 
 template <typename U, int E, int FUSE>
 static int row_panel_launch(const LinearArgs& a, const RowPanelFuse& f, hipStream_t s) {
+  static_assert((FUSE & FUSE_MX) == 0 || (FUSE & FUSE_LN) != 0, "MX output = LayerNorm output");
   const int tiles_total = a.M / 96, want = (tiles_total + 7) & ~7;
   const dim3 grid(static_cast<unsigned>(want < 256 ? want : 256));
   const size_t lds = 2 * static_cast<size_t>(96 + 512) * ROW_BYTES + 2 * 96 * 8 * sizeof(float);
@@ -676,7 +730,7 @@ static int row_panel_launch(const LinearArgs& a, const RowPanelFuse& f, hipStrea
   }
   RowPanelArgs<U> rp{static_cast<const U*>(f.X2), static_cast<const U*>(f.lnw), static_cast<const U*>(f.lnb),
                      static_cast<const U*>(f.lnw2), static_cast<const U*>(f.lnb2), static_cast<const U*>(f.film),
-                     static_cast<U*>(f.lny), static_cast<U*>(f.lny2), f.eps};
+                     static_cast<U*>(f.lny), static_cast<U*>(f.lny2), f.eps, static_cast<uint8_t*>(f.sx), static_cast<uint8_t*>(f.sx2)};
   gemm_mfma_big<U, E, 1, 8, 1, FUSE><<<grid, dim3(512), lds, s>>>(
       static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
       static_cast<const U*>(a.R1), nullptr, a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, 1, tiles_total, nullptr, rp);
@@ -690,11 +744,13 @@ int row_panel_linear(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipS
     using U = std::remove_pointer_t<decltype(tag)>;
     switch (kind) {
       case 1:
+        if (f.sx) return row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2 | FUSE_MX>(a, f, s);
 #ifdef D3PM_ABLATIONS
         if (big_gemm_mode() == 1025) return row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2 | FUSE_ABL_NOLN>(a, f, s);
 #endif
         return row_panel_launch<U, EPI_R1, FUSE_LN | FUSE_LN2>(a, f, s);
-      case 2: return row_panel_launch<U, EPI_R2, FUSE_DUAL | FUSE_LN | FUSE_FILM>(a, f, s);
+      case 2: return f.sx ? row_panel_launch<U, EPI_R2, FUSE_DUAL | FUSE_LN | FUSE_FILM | FUSE_MX>(a, f, s)
+                          : row_panel_launch<U, EPI_R2, FUSE_DUAL | FUSE_LN | FUSE_FILM>(a, f, s);
       case 3: return row_panel_launch<U, EPI_R1 | EPI_MASK, FUSE_LN>(a, f, s);
       default: break;
     }

@@ -29,29 +29,12 @@
 // rn_e4m3(x / scale) never saturate.
 #include "d3pm_kernels.h"
 #include "d3pm_mfma_tile.h"
+#include "d3pm_mx.h"
 
 namespace d3pm {
 namespace {
 
 typedef int intx8 __attribute__((ext_vector_type(8)));
-
-// ---- e8m0 block scale of an absolute maximum -------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mx_scale_byte(float amax) {
-  const uint32_t b = __float_as_uint(amax);
-  int e = static_cast<int>(b >> 23) - 8 + ((b & 0x7FFFFFu) > 0x600000u ? 1 : 0);
-  e = e < 1 ? 1 : (e > 254 ? 254 : e);               // amax = 0 (or denormal) -> the smallest scale: every code is 0
-  return static_cast<uint32_t>(e);
-}
-__device__ __forceinline__ float mx_inv_scale(uint32_t byte) { return __uint_as_float((254u - byte) << 23); }   // 2^(127 - byte), exact
-
-__device__ __forceinline__ uint2 mx_pack8(const float (&o)[8], float inv) {
-  uint32_t lo = 0, hi = 0;
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0] * inv, o[1] * inv, lo, false);
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2] * inv, o[3] * inv, lo, true);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4] * inv, o[5] * inv, hi, false);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6] * inv, o[7] * inv, hi, true);
-  return uint2{lo, hi};
-}
 
 template <typename T> struct alignas(16) Vec8 { T v[8]; };
 
@@ -297,7 +280,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mx_big(const uint8_t* __
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
-    using INST = std::integral_constant<int, OUT8 ? 24 : 12>;       // stores of an epilogue per wave (OUT8: 12 code + 12 scale stores)
+    using INST = std::integral_constant<int, 12>;       // stores of an epilogue per wave (MX output: 6 code + 6 scale stores)
     for (int c = 0; c < nchunk; ++c) {
       const int k0 = c * 512;
       const bool last = c + 1 == nchunk;
@@ -316,23 +299,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mx_big(const uint8_t* __
       // (n0 + wn * 64) / 128 of the consumer's K = N.
       uintx4 packed[12];
       epilogue_store<T, EPI, 4, 6, true, true>(acc, bias, Y, ldy, nullptr, nullptr, ldr, nullptr, 1, M, N, m0 + wm * 96, n0 + wn * 64, lane, packed);
-      const int nq = epilogue_nq(lane), nks = N / 128;
+      const int nks = N / 128, col0 = n0 + wn * 64;
 #pragma unroll
-      for (int mt = 0; mt < 6; ++mt)
+      for (int mt = 0; mt < 6; ++mt) {
+        uint2 cd[2];
+        uint32_t sb[2];
 #pragma unroll
         for (int np = 0; np < 2; ++np) {
           const Pack8<T> p = __builtin_bit_cast(Pack8<T>, packed[mt * 2 + np]);
-          float v[8], amax = 0.f;
+          float v[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) { v[i] = static_cast<float>(p.v[i]); amax = fmaxf(amax, fabsf(v[i])); }
-          amax = fmaxf(amax, __shfl_xor(amax, 16, kWave));
-          amax = fmaxf(amax, __shfl_xor(amax, 32, kWave));
-          const uint32_t sb = mx_scale_byte(amax);
-          const int row = m0 + wm * 96 + mt * 16 + (lane & 15), col = n0 + wn * 64 + np * 32;
-          *reinterpret_cast<uint2*>(Y8 + static_cast<size_t>(row) * N + col + nq) = mx_pack8(v, mx_inv_scale(sb));
-          // every lane issues the byte store (same address and value within a block's four lanes): a fixed count of stores per wave
-          SY[(static_cast<size_t>(row) * 4 + ((col >> 5) & 3)) * nks + (col >> 7)] = static_cast<uint8_t>(sb);
+          for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(p.v[i]);
+          cd[np] = mx_block_quantise(v, sb[np]);
         }
+        const int row = m0 + wm * 96 + mt * 16 + (lane & 15);
+        mx_store_row64(cd[0], cd[1], Y8 + static_cast<size_t>(row) * N + col0, lane);
+        // the row's two block scales: lanes g = 0 / 1 write the byte of half 0 / 1 (one store instruction)
+        if (lane < 32) {
+          const int blk = (col0 >> 5) + (lane >> 4);
+          SY[(static_cast<size_t>(row) * 4 + (blk & 3)) * nks + (blk >> 2)] = static_cast<uint8_t>(lane < 16 ? sb[0] : sb[1]);
+        }
+      }
     } else {
       epilogue_store<T, EPI, 4, 6, true, false>(acc, bias, Y, ldy, R1, nullptr, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
                                                 n0 + wn * 64, lane);
@@ -352,6 +339,9 @@ inline bool aligned16m(const void* p) { return (reinterpret_cast<uintptr_t>(p) %
 
 // geometry: 2 = 192 x 256 (eight waves, one workgroup per CU), 3 = 192 x 128 (four waves, two per CU)
 static int mx_geometry(const MxLinearArgs& a) {
+  const int want = tune_of(a.tune).gemm_variant;          // 6 / 8: only the 192 x 256 / 192 x 128 tile (as for the 16-bit big tiles)
+  if (want == 6) return (a.M % 192 == 0 && a.N % 256 == 0) ? 2 : 0;
+  if (want == 8) return (a.M % 192 == 0 && a.N % 128 == 0) ? 3 : 0;
   auto fits = [&](int tm, int tn, int slots) {
     if (a.M % tm != 0 || a.N % tn != 0) return false;
     const long long tiles = static_cast<long long>(a.M / tm) * (a.N / tn), rounds = (tiles + slots - 1) / slots;

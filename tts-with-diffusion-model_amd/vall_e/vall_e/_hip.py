@@ -129,7 +129,7 @@ SIGNATURES = {
                                        C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "d3pm_op_linear_mx": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                    C.c_int, C.c_void_p]),
+                                    C.c_int, C.POINTER(Tuning), C.c_void_p]),
     "d3pm_ce_loss_rows": (C.c_int, [C.POINTER(Shape), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "d3pm_uniform": (C.c_int, [C.c_uint64, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -147,7 +147,7 @@ SIGNATURES = {
                                     C.c_int, C.c_float, C.c_void_p]),
     "d3pm_op_linear_rowpanel": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "d3pm_op_cond_embed": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p]),
     "d3pm_op_matmul_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_int, C.c_int,
@@ -381,7 +381,10 @@ class Sampler:
         self.shape = make_shape(cfg, dtype)
         self.weights = DeviceWeights(tensors, cfg.n_layers)
         self._tensors, self._fp8 = tensors, None
-        self.fp8_fc2 = True        # the fp8 fast path also runs fc2 on MX operands (fc1 writes the hidden layer in that format)
+        # fp8 fast path: also run fc2 on MX operands (fc1's GELU epilogue then writes the hidden layer in that format)?  Off: measured
+        # on MI355X the quantising GELU epilogue costs fc1 what fc2 gains (72 + 38 us vs 63 + 46 us per block) and the logits error
+        # grows from 3.1 % to 3.6 % (profiles/round3_d_*); the kernels and their tests stay
+        self.fp8_fc2 = False
         self.cond_weights = (DeviceCondWeights(tensors, cfg, pe_text0, pe_prompt)
                              if pe_text0 is not None and "encodertext.1.fc1.weight" in tensors else None)
         self._cond_ws = None
@@ -663,7 +666,7 @@ def op_linear_mx(x8, sx, w8, sw, bias, out_dtype, *, act=0, r1=None, row_mask=No
         y = torch.empty((M, N), dtype=out_dtype, device=x8.device)
     check(lib().d3pm_op_linear_mx(dtype_code(out_dtype), _p(x8), x8.stride(0), _p(sx), _p(w8), _p(sw), _p(bias), _p(y), N, _p(r1),
                                   0 if r1 is None else r1.stride(0), _p(row_mask), mask_period, _p(y8), _p(sy), M, N, K, act,
-                                  stream_ptr()), "d3pm_op_linear_mx")
+                                  C.byref(TUNING), stream_ptr()), "d3pm_op_linear_mx")
     return (y8, sy) if mx_out else y
 
 
@@ -702,19 +705,31 @@ def op_linear_lnpro(x, w, bias, ln_w, ln_b, *, ln2_w=None, ln2_b=None, film=None
     return y
 
 
-def op_linear_rowpanel(x, w, bias, r1, ln_w, ln_b, *, x2=None, ln2_w=None, ln2_b=None, film=None, row_mask=None, eps=1e-6):
+def op_linear_rowpanel(x, w, bias, r1, ln_w, ln_b, *, x2=None, ln2_w=None, ln2_b=None, film=None, row_mask=None, eps=1e-6, mx=False):
     """Projection onto the residual stream + the LayerNorm(s) of the new rows in one launch (include/d3pm_hip.h).
-    Returns (y, ln_y, ln2_y | None)."""
+    Returns (y, ln_y, ln2_y | None); with mx=True the LayerNorm rows come back in the block-scaled fp8 format:
+    (y, (codes, scales), (codes2, scales2) | None)."""
     M, K = x.shape
     if not (tuple(w.shape) == (512, K) and tuple(r1.shape) == (M, 512) and x.stride(1) == 1 and w.is_contiguous() and r1.is_contiguous()):
         raise ValueError("op_linear_rowpanel: x [M,K], w [512,K], r1 [M,512]")
     if x2 is not None and (x2.shape != x.shape or x2.stride() != x.stride()):
         raise ValueError("op_linear_rowpanel: x2 must look like x")
-    y, ln_y = torch.empty_like(r1), torch.empty_like(r1)
-    ln2_y = torch.empty_like(r1) if ln2_w is not None else None
+    y = torch.empty_like(r1)
+    if mx:
+        ln_y = torch.empty((M, 512), dtype=torch.uint8, device=x.device)
+        ln2_y = torch.empty_like(ln_y) if ln2_w is not None else None
+        sx = torch.empty((M, 4, 4), dtype=torch.uint8, device=x.device)
+        sx2 = torch.empty_like(sx) if ln2_w is not None else None
+    else:
+        ln_y = torch.empty_like(r1)
+        ln2_y = torch.empty_like(r1) if ln2_w is not None else None
+        sx = sx2 = None
     check(lib().d3pm_op_linear_rowpanel(dtype_code(x.dtype), _p(x), _p(x2), x.stride(0), _p(w), _p(bias), _p(y), _p(r1), _p(row_mask),
                                         0 if row_mask is None else row_mask.numel(), M, K, _p(ln_w), _p(ln_b), _p(ln_y),
-                                        _p(ln2_w), _p(ln2_b), _p(ln2_y), _p(film), eps, stream_ptr()), "d3pm_op_linear_rowpanel")
+                                        _p(ln2_w), _p(ln2_b), _p(ln2_y), _p(film), eps, _p(sx), _p(sx2), stream_ptr()),
+          "d3pm_op_linear_rowpanel")
+    if mx:
+        return y, (ln_y, sx), ((ln2_y, sx2) if ln2_w is not None else None)
     return y, ln_y, ln2_y
 
 
