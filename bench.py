@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path with several ranks sharing one GPU (NCCL refuses that)")
     ap.add_argument("--no-nar", action="store_true", help="skip the extra NAR (levels 1..7) measurement")
+    ap.add_argument("--no-nq8", action="store_true", help="skip the extra n_q = 8 extension measurement")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8 fast-path measurement (BASELINE.json configs[4])")
     ap.add_argument("--streams", type=int, default=1, help="independent batch chunks on separate HIP streams")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -209,6 +210,30 @@ def host_cpu_info(cores):
         rates[name] = 2.0 * 768 * 512 * 2048 * reps / (time.perf_counter() - t0) / 1e9
     return {"cpu_model": model, "logical_cpus": os.cpu_count(), "threads_granted": cores,
             "torch_parallel_info": par[:12], "eager_linear_768x512x2048_gflops": rates}
+
+
+def n_q8_extension(dev, dtype, batch, texts, proms):
+    """SURVEY.md section 8d config 2, second form (BASELINE.json configs[1] "750 codec frames x 8 quantizers"): the D3PM
+    denoising all 8 quantizer levels of a frame jointly (AR(..., n_q=8): summed level embeddings in, 8 x 1025 logits out, every
+    (frame, level) sampled like a level-0 token).  An extension of this build -- the reference generates level 0 only -- so
+    it is reported beside `value`, never inside it."""
+    from vall_e.vall_e import AR, synth
+    cfg8 = synth.D3PMConfig.libritts_8q()
+    m = AR.from_config(cfg8)
+    m.load_state_dict(synth.make_state_dict(cfg8, 0))
+    m = m.to(dtype).to(dev)
+    m.generate_audio(texts, proms, seed=1)
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for i in range(reps):
+        out = m.generate_audio(texts, proms, seed=2 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert out.shape == (batch, cfg8.canvas, 8)
+    return {"model": "D3PM n_q=8 (extension; no reference counterpart)", "seconds_per_batch": dt, "repetitions": reps,
+            "codec_tokens_per_s": 8 * batch * cfg8.n_frames / dt,
+            "unmasked_fraction": float((out[:, : cfg8.n_frames] != cfg8.mask_id).float().mean())}
 
 
 def cpu_baseline(cfg, sd32, texts, proms, n_iters):
@@ -419,6 +444,9 @@ def main():
             d3pm_s = ms_per_step * 1e-3
             result["nar_levels_1to7"]["all_8_levels_codec_tokens_per_s"] = (
                 8 * batch * cfg.n_frames / (d3pm_s + result["nar_levels_1to7"]["seconds_per_batch"]))
+        if world == 1 and not args.no_nq8 and args.config == "libritts" and dtype != torch.float32:
+            note("measuring the n_q = 8 extension")
+            result["n_q8_extension"] = n_q8_extension(dev, dtype, batch, texts, proms)
         if world == 1 and not args.no_fp8 and args.config == "libritts" and dtype != torch.float32:
             note("measuring the fp8 / 50-step fast path")
             result["fp8_fast_path"] = fp8_fast_path(dev, dtype, batch, cfg, sd32, texts, proms)

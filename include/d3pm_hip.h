@@ -116,6 +116,13 @@ typedef struct d3pm_shape {
   int32_t mask_id;    /* absorbing id 512 (:332)                                                   */
   int32_t timesteps;  /* 100 (:207); the loop runs t = timesteps-1 .. 1 (:750)                     */
   int32_t dtype;      /* D3PM_F32 / D3PM_F16 / D3PM_BF16                                           */
+  int32_t n_q;        /* quantizer levels the D3PM generates jointly: 0 or 1 = level 0 only, as upstream (:699-709,
+                         SURVEY.md section 0 #4).  n_q > 1 is this build's extension (SURVEY section 8d config 2,
+                         BASELINE.json configs[1] "x 8 quantizers"; no reference counterpart): token grids are
+                         [batch][canvas][n_q], a frame's input embedding is the sum of its n_q level embeddings
+                         (resps_emb [n_q][n_classes][d], as MultiEmbedding sums the prompt levels, base.py:244-274), `final`
+                         is [n_q * n_classes][d] and every (frame, level) is sampled like a level-0 token, level l > 0 on
+                         Philox stream 16 + l.  With n_q = 1 every entry point is bit-identical to the level-0 path. */
   const d3pm_tuning *tuning;   /* schedule choices of the calls made with this shape, or NULL (defaults)   */
 } d3pm_shape;
 
@@ -137,9 +144,9 @@ typedef struct d3pm_block_weights {
 } d3pm_block_weights;
 
 typedef struct d3pm_weights {
-  const void *resps_emb;                  /* [n_classes][d]  (:212)                       */
+  const void *resps_emb;                  /* [n_classes][d]  (:212); n_q > 1: [n_q][n_classes][d] */
   const void *time_emb;                   /* [timesteps+1][d] (:213)                      */
-  const void *final_w, *final_b;          /* [n_classes][d], [n_classes] (:240)           */
+  const void *final_w, *final_b;          /* [n_classes][d], [n_classes] (:240); n_q > 1: [n_q * n_classes][d], [n_q * n_classes] */
   const d3pm_block_weights *blocks;       /* HOST array of n_layers entries               */
 } d3pm_weights;
 

@@ -225,3 +225,22 @@ def test_training_gradients_of_the_oracle_match_the_references_autograd():
         scale = max(np.abs(want[2:]).max(), want[1] / flat.numel(), 1e-12)
         assert np.abs(flat[idx].numpy() - want[2:]).max() <= 1e-4 * scale + 1e-10, (name, flat[idx].numpy(), want[2:])
         assert abs(flat.abs().sum().item() - want[1]) <= 1e-4 * want[1] + 1e-12, (name, flat.abs().sum().item(), want[1])
+
+
+def test_n_q_extension_oracle_reduces_to_the_pinned_oracle_at_n_q_1():
+    """oracle/d3pm_nq_oracle.py (the build's definition of the n_q > 1 extension) with a level-0-only state dict: the same
+    logits and the same sampled ids as oracle/d3pm_oracle.py, bit for bit."""
+    from oracle import d3pm_nq_oracle as NQ
+    from vall_e.vall_e import synth
+    cfg = synth.D3PMConfig.native()
+    sd = {k: v.half() for k, v in synth.make_state_dict(cfg, 0).items()}
+    texts, proms = synth.make_inputs(cfg, 1, 1)
+    shape = O.Shape.of(cfg)
+    orc = O.Oracle(sd, shape)
+    a = orc.generate(texts[0], proms[0], O.philox_noise(9, cfg.canvas), t_start=3)
+    b = NQ.generate(sd, shape, texts[0], proms[0], 9, t_start=3)
+    assert b.shape == (cfg.canvas, 1) and torch.equal(b[:, 0], a)
+    x, mask = orc.canvas_init()
+    with torch.no_grad():
+        cp, ct = orc.conditions(texts[0], proms[0])
+        assert torch.equal(NQ.logits(sd, shape, x[:, None], 50, cp, ct, mask)[:, 0], orc.logits(x, 50, cp, ct, mask))

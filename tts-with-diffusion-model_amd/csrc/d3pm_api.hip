@@ -152,6 +152,8 @@ struct Workspace {
 static size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 // internal logits rows are padded to a multiple of 8 elements (16-B aligned rows for vector stores/loads)
 static int logits_ld(const d3pm_shape& sh) { return (sh.n_classes + 7) & ~7; }
+// quantizer levels generated jointly (d3pm_shape.n_q; 0 and 1 = the upstream level-0 path)
+static int levels(const d3pm_shape& sh) { return sh.n_q > 1 ? sh.n_q : 1; }
 static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
   const size_t es = dtype_size(sh.dtype), n = static_cast<size_t>(batch) * sh.canvas, d = sh.d_model;
   Workspace w{};
@@ -165,7 +167,7 @@ static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
   //   packed qkv rows -> cross-attention queries -> MLP hidden rows -> logits of the iteration;
   //   norm22 output (dead once the query projection ran) -> prompt cross-attention output
   if (tune_of(sh.tuning).workspace_alias) {
-    const size_t big = n * 4 * d * es, lg = n * logits_ld(sh) * es;
+    const size_t big = n * 4 * d * es, lg = n * levels(sh) * logits_ld(sh) * es;
     w.mlp = take(big > lg ? big : lg);
     w.qkv = w.mlp;
     w.logits = w.mlp;
@@ -176,7 +178,7 @@ static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
     w.att = take(n * d * es);
     w.att2 = take(n * d * es);
     w.mlp = take(n * 4 * d * es);
-    w.logits = take(n * logits_ld(sh) * es);
+    w.logits = take(n * levels(sh) * logits_ld(sh) * es);
   }
   w.total = off;
   return w;
@@ -186,7 +188,7 @@ static int check_shape(const d3pm_shape* sh, int batch) {
   D3PM_REQUIRE(sh, D3PM_E_ARG, "null shape");
   D3PM_REQUIRE(batch > 0 && sh->d_model > 0 && sh->n_heads > 0 && sh->d_model % sh->n_heads == 0 && sh->n_layers > 0 &&
                    sh->canvas > 0 && sh->s_text > 0 && sh->s_prompt > 0 && sh->n_classes > 1 && sh->mask_id >= 0 &&
-                   sh->mask_id < sh->n_classes && sh->timesteps >= 2,
+                   sh->mask_id < sh->n_classes && sh->timesteps >= 2 && sh->n_q >= 0 && sh->n_q <= 16,
                D3PM_E_ARG, "inconsistent d3pm_shape");
   D3PM_REQUIRE(sh->dtype == D3PM_F32 || sh->dtype == D3PM_F16 || sh->dtype == D3PM_BF16, D3PM_E_ARG, "bad dtype %d",
                sh->dtype);
@@ -241,11 +243,11 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
 
   EmbedArgs e;
   e.tokens = x_t; e.frame_mask = frame_mask; e.canvas = T; e.table = w.resps_emb; e.Y = ws.x;
-  e.M = n; e.d = d; e.n_classes = sh.n_classes;
+  e.M = n; e.d = d; e.n_classes = sh.n_classes; e.n_q = levels(sh);
   // the first block's norm1 reads the embedding rows straight from the table and writes x beside its own output: one launch and
   // one pass over x less per iteration (same bits: the gather is a copy)
   bool embed_fused = false;
-  if (!use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && layers > 0) {
+  if (!use8 && !(flags & D3PM_FLAG_FORCE_GENERIC) && layers > 0 && levels(sh) == 1) {
     LayerNormArgs ln0;
     ln0.X = w.resps_emb; ln0.Y = ws.h; ln0.w = w.blocks[0].norm1_w; ln0.b = w.blocks[0].norm1_b; ln0.M = n; ln0.d = d; ln0.eps = 1e-6f;
     ln0.tokens = x_t; ln0.frame_mask = frame_mask; ln0.canvas = T; ln0.n_classes = sh.n_classes; ln0.Xout = ws.x;
@@ -432,7 +434,7 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
 // the fused final + sampler kernel takes over wherever the final projection would have run on the MFMA family
 static bool fused_final_sample_applies(const d3pm_shape& sh, const d3pm_weights& w, const Workspace& ws, uint32_t flags) {
 #ifdef D3PM_ABLATIONS
-  return ab_knobs().fused_final_sample && !(flags & D3PM_FLAG_FORCE_GENERIC) && sh.d_model >= 64 &&
+  return ab_knobs().fused_final_sample && !(flags & D3PM_FLAG_FORCE_GENERIC) && sh.d_model >= 64 && levels(sh) == 1 &&
          final_sample_supported(sh.dtype, sh.n_classes, sh.d_model, ws.x, sh.d_model, w.final_w);
 #else
   return false;      // built, bit-identical, 253 us vs 30 + 87 us: lives in libd3pm_hip_ab.so only (include/d3pm_hip_ab.h)
@@ -441,12 +443,18 @@ static bool fused_final_sample_applies(const d3pm_shape& sh, const d3pm_weights&
 
 static int final_logits(const d3pm_shape& sh, const d3pm_weights& w, int batch, const Workspace& ws, void* logits,
                         int ldl, uint32_t flags, hipStream_t s) {
-  // x is already multiplied by the frame mask at the end of every block (ar_discrete.py:161,773)
-  LinearArgs g;
-  g.X = ws.x; g.ldx = sh.d_model; g.W = w.final_w; g.bias = w.final_b; g.Y = logits; g.ldy = ldl;
-  g.M = batch * sh.canvas; g.N = sh.n_classes; g.K = sh.d_model;
+  // x is already multiplied by the frame mask at the end of every block (ar_discrete.py:161,773).
+  // n_q > 1: one projection per level (final_w [n_q][n_classes][d]) into the level's [ldl]-wide slot of a frame's n_q * ldl logits
   const Ctx cx(sh.tuning);
-  return run_linear(cx, sh.dtype, g, flags, s);
+  const size_t es = dtype_size(sh.dtype);
+  for (int l = 0; l < levels(sh); ++l) {
+    LinearArgs g;
+    g.X = ws.x; g.ldx = sh.d_model; g.W = at(w.final_w, static_cast<size_t>(l) * sh.n_classes * sh.d_model, es);
+    g.bias = at(w.final_b, static_cast<size_t>(l) * sh.n_classes, es); g.Y = at(logits, static_cast<size_t>(l) * ldl, es);
+    g.ldy = levels(sh) * ldl; g.M = batch * sh.canvas; g.N = sh.n_classes; g.K = sh.d_model;
+    D3PM_TRY(run_linear(cx, sh.dtype, g, flags, s));
+  }
+  return D3PM_OK;
 }
 
 }  // namespace d3pm
@@ -605,7 +613,7 @@ static int denoise_step_impl(const d3pm_shape* sh, const d3pm_weights* w, int ba
     const size_t es = dtype_size(sh->dtype);
     D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, logits_ld(*sh), flags, s));
     D3PM_CHECK_HIP(hipMemcpy2DAsync(logits_out, sh->n_classes * es, ws.logits, logits_ld(*sh) * es, sh->n_classes * es,
-                                    static_cast<size_t>(batch) * sh->canvas, hipMemcpyDeviceToDevice, s));
+                                    static_cast<size_t>(batch) * sh->canvas * levels(*sh), hipMemcpyDeviceToDevice, s));
   }
   return D3PM_OK;
 }
@@ -636,7 +644,8 @@ int d3pm_posterior_sample(const d3pm_shape* sh, int batch, const void* logits, i
   D3PM_REQUIRE(t >= 0 && t < sched->timesteps, D3PM_E_ARG, "t=%d outside the schedule", t);
   SampleArgs a;
   a.logits = logits; a.logits_dtype = logits_dtype; a.ldl = sh->n_classes; a.x_t = x_t; a.x_next = x_next;
-  a.posterior_out = posterior_out; a.rows = batch * sh->canvas; a.n_classes = sh->n_classes; a.mask_id = sh->mask_id;
+  a.posterior_out = posterior_out; a.rows = batch * sh->canvas * levels(*sh); a.n_classes = sh->n_classes; a.mask_id = sh->mask_id;
+  a.n_q = levels(*sh);
   a.canvas = sh->canvas; a.seed = seed; a.row0 = utt0 * static_cast<uint32_t>(sh->canvas);
   a.greedy = (flags & D3PM_FLAG_GREEDY) ? 1 : 0; a.pc = make_posterior_consts(sched, t);
   return posterior_sample(a, static_cast<hipStream_t>(stream));
@@ -661,8 +670,8 @@ static int sample_loop_impl(const d3pm_shape* sh, const d3pm_weights* w, int bat
     D3PM_TRY(denoiser_blocks(*sh, *w, batch, x, frame_mask, t, film, kv_text, kv_prompt, ws, sh->n_layers, flags, s, f8));
     SampleArgs a;
     a.logits = ws.logits; a.logits_dtype = sh->dtype; a.ldl = logits_ld(*sh); a.x_t = x; a.x_next = x;
-    a.x_next2 = trace ? trace + static_cast<size_t>(t_start - t) * rows : nullptr;
-    a.rows = rows; a.n_classes = sh->n_classes; a.mask_id = sh->mask_id; a.canvas = sh->canvas; a.seed = seed;
+    a.x_next2 = trace ? trace + static_cast<size_t>(t_start - t) * rows * levels(*sh) : nullptr;
+    a.rows = rows * levels(*sh); a.n_q = levels(*sh); a.n_classes = sh->n_classes; a.mask_id = sh->mask_id; a.canvas = sh->canvas; a.seed = seed;
     if (flags & D3PM_FLAG_SEED_IN_HBM) a.seed_hbm = reinterpret_cast<const uint64_t*>(static_cast<uintptr_t>(seed));
     a.row0 = utt0 * static_cast<uint32_t>(sh->canvas); a.greedy = (flags & D3PM_FLAG_GREEDY) ? 1 : 0;
     a.pc = make_posterior_consts(sched, t);
@@ -679,7 +688,7 @@ static int sample_loop_impl(const d3pm_shape* sh, const d3pm_weights* w, int bat
     {
       D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, logits_ld(*sh), flags, s));
       ProfScope p(cx, D3PM_K_SAMPLE, s, 0.0,
-                  static_cast<double>(rows) * (sh->n_classes * dtype_size(sh->dtype) + 8.0));
+                  static_cast<double>(rows) * levels(*sh) * (sh->n_classes * dtype_size(sh->dtype) + 8.0));
       D3PM_TRY(posterior_sample(a, s));
     }
   }
@@ -708,6 +717,7 @@ int d3pm_q_sample(const d3pm_shape* sh, int batch, const int32_t* x0, int32_t* x
                   const d3pm_schedule* sched, uint64_t seed, uint32_t utt0, void* stream) {
   D3PM_TRY(check_shape(sh, batch));
   D3PM_REQUIRE(x0 && x_out && frame_mask && sched && sched->dbar && sched->cbar, D3PM_E_ARG, "d3pm_q_sample: null pointer");
+  D3PM_REQUIRE(levels(*sh) == 1, D3PM_E_SHAPE, "d3pm_q_sample: the training side covers the upstream level-0 model only (n_q = 1)");
   D3PM_REQUIRE(t >= 0 && t < sched->timesteps, D3PM_E_ARG, "t=%d outside the schedule", t);
   return q_sample_launch(sh, batch, x0, x_out, frame_mask, t, sched, seed, utt0, static_cast<hipStream_t>(stream));
 }
@@ -716,6 +726,7 @@ int d3pm_ce_loss_rows(const d3pm_shape* sh, int batch, const void* logits, int l
                       const uint8_t* frame_mask, float* row_loss, void* stream) {
   D3PM_TRY(check_shape(sh, batch));
   D3PM_REQUIRE(logits && targets && frame_mask && row_loss, D3PM_E_ARG, "d3pm_ce_loss_rows: null pointer");
+  D3PM_REQUIRE(levels(*sh) == 1, D3PM_E_SHAPE, "d3pm_ce_loss_rows: the training side covers the upstream level-0 model only (n_q = 1)");
   return ce_loss_launch(logits_dtype, logits, sh->n_classes, targets, frame_mask, sh->canvas, batch * sh->canvas,
                         sh->n_classes, row_loss, static_cast<hipStream_t>(stream));
 }

@@ -32,6 +32,26 @@ __global__ void embed_rows(const int32_t* __restrict__ tok, const uint8_t* __res
   for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = live ? src[c] : static_cast<T>(0.f);
 }
 
+// n_q > 1 (d3pm_shape.n_q, this build's extension): a frame's row is the sum of its n_q level embeddings, accumulated in fp32 in
+// level order and rounded once -- what MultiEmbedding does for the prompt levels (base.py:244-274)
+template <typename T>
+__global__ void embed_levels_rows(const int32_t* __restrict__ tok, const uint8_t* __restrict__ frame_mask, int canvas,
+                                  const T* __restrict__ tables, T* __restrict__ y, int M, int d, int n_classes, int n_q) {
+  const int row = blockIdx.x;
+  if (row >= M) return;
+  const bool live = frame_mask[row % canvas] != 0;
+  T* dst = y + static_cast<size_t>(row) * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float acc = 0.f;
+    for (int l = 0; l < n_q; ++l) {
+      int id = tok[static_cast<size_t>(row) * n_q + l];
+      id = id < 0 ? 0 : (id >= n_classes ? n_classes - 1 : id);
+      acc += static_cast<float>(tables[(static_cast<size_t>(l) * n_classes + id) * d + c]);
+    }
+    dst[c] = live ? static_cast<T>(acc) : static_cast<T>(0.f);
+  }
+}
+
 // the same gather with 16-byte accesses: one wave per row, four rows per workgroup (rows of 16-byte multiples)
 template <typename T>
 __global__ __launch_bounds__(256) void embed_rows_vec(const int32_t* __restrict__ tok, const uint8_t* __restrict__ frame_mask,
@@ -267,6 +287,12 @@ template <typename F> int dispatch(int dtype, F&& f) {
 int embed_tokens(int dtype, const EmbedArgs& a, hipStream_t s) {
   return dispatch(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
+    if (a.n_q > 1) {
+      embed_levels_rows<T><<<a.M, a.d >= 256 ? 256 : 64, 0, s>>>(a.tokens, a.frame_mask, a.canvas, static_cast<const T*>(a.table),
+                                                              static_cast<T*>(a.Y), a.M, a.d, a.n_classes, a.n_q);
+      D3PM_LAUNCH_CHECK();
+      return D3PM_OK;
+    }
     const bool vec = (a.d * sizeof(T)) % 16 == 0 && reinterpret_cast<uintptr_t>(a.table) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(a.Y) % 16 == 0 && a.d * sizeof(T) >= 256;
     if (vec) {

@@ -94,6 +94,7 @@ struct LnPrologue {
 struct EmbedArgs {
   const int32_t* tokens = nullptr; const uint8_t* frame_mask = nullptr; int canvas = 0;
   const void* table = nullptr; void* Y = nullptr; int M = 0, d = 0, n_classes = 0;
+  int n_q = 1;      // > 1: tokens [M][n_q], table [n_q][n_classes][d], row = rn(sum over the levels) (d3pm_shape.n_q)
 };
 
 // per-step scalars of the closed-form posterior (host-built from d3pm_schedule)
@@ -114,6 +115,7 @@ struct SampleArgs {
   int rows = 0, n_classes = 0, mask_id = 0, canvas = 0;
   uint64_t seed = 0; uint32_t row0 = 0; int greedy = 0;
   const uint64_t* seed_hbm = nullptr;   // when set, the kernel reads the seed from HBM (lets a captured HIP graph be replayed with a new seed)
+  int n_q = 1;      // > 1: row r = (frame row r / n_q, level r % n_q); Philox row = row0 + frame row, stream = level ? 16 + level : 0
   PosteriorConsts pc{};
 };
 

@@ -29,14 +29,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void posterior_sample_rows(
     const T* __restrict__ logits, int ldl, const int32_t* x_t, int32_t* x_next,
     int32_t* x_next2, uint16_t* __restrict__ post_out, int rows, int K, int mask_id,
-    uint64_t seed, const uint64_t* __restrict__ seed_hbm, uint32_t row0, int greedy, PosteriorConsts pc) {
+    uint64_t seed, const uint64_t* __restrict__ seed_hbm, uint32_t row0, int greedy, PosteriorConsts pc, int n_q) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + wave;
   if (row >= rows) return;
   if (seed_hbm) seed = *seed_hbm;
+  // n_q > 1 (d3pm_shape.n_q): row = frame row * n_q + level; the level-0 token of a frame draws the noise the level-0-only
+  // path draws, level l > 0 draws from Philox stream 16 + l at the same (frame row, t)
+  const int frow = n_q > 1 ? row / n_q : row, level = row - frow * (n_q > 1 ? n_q : 1);
   const int best_j = sample_row<T>(logits + static_cast<size_t>(row) * ldl, K, mask_id, x_t[row], seed,
-                                   row0 + static_cast<uint32_t>(row), greedy, pc,
-                                   post_out ? post_out + static_cast<size_t>(row) * K : nullptr, lane);
+                                   row0 + static_cast<uint32_t>(frow), greedy, pc,
+                                   post_out ? post_out + static_cast<size_t>(row) * K : nullptr, lane,
+                                   level ? 16u + static_cast<uint32_t>(level) : 0u);
   if (lane == 0) {
     x_next[row] = best_j;
     if (x_next2) x_next2[row] = best_j;
@@ -100,7 +104,7 @@ int posterior_sample(const SampleArgs& a, hipStream_t s) {
 #define D3PM_PS(T)                                                                                      \
   posterior_sample_rows<T><<<grid, block, 0, s>>>(static_cast<const T*>(a.logits), a.ldl, a.x_t, a.x_next, \
                                                   a.x_next2, a.posterior_out, a.rows, a.n_classes,        \
-                                                  a.mask_id, a.seed, a.seed_hbm, a.row0, a.greedy, a.pc)
+                                                  a.mask_id, a.seed, a.seed_hbm, a.row0, a.greedy, a.pc, a.n_q)
   switch (a.logits_dtype) {
     case D3PM_F32: D3PM_PS(float); break;
     case D3PM_F16: D3PM_PS(f16); break;

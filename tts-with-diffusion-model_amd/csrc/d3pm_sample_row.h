@@ -16,7 +16,7 @@ constexpr float kEps = 1.0e-6f;        // self.eps (ar_discrete.py:276), added i
 // returns the sampled id in every lane.  `post_row` (optional) receives the fp16 posterior logits of the row.
 template <typename T, typename P>
 __device__ __forceinline__ int sample_row(P lr, int K, int mask_id, int x, uint64_t seed, uint32_t grow, int greedy,
-                                          const PosteriorConsts& pc, uint16_t* post_row, int lane) {
+                                          const PosteriorConsts& pc, uint16_t* post_row, int lane, uint32_t stream = 0u) {
   const int groups = (K + 3) >> 2;
   float z[kMaxGroupsPerLane][4];
   float mx = -INFINITY;
@@ -73,7 +73,7 @@ __device__ __forceinline__ int sample_row(P lr, int K, int mask_id, int x, uint6
       int g = lane + i * kWave;
       if (g >= groups) continue;
       float u[4];
-      if (!greedy) noise4(seed, static_cast<uint32_t>(g), grow, static_cast<uint32_t>(pc.t), 0u, u);
+      if (!greedy) noise4(seed, static_cast<uint32_t>(g), grow, static_cast<uint32_t>(pc.t), stream, u);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         int j = g * 4 + w;

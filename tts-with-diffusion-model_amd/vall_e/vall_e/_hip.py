@@ -33,7 +33,7 @@ class Tuning(C.Structure):
 
 class Shape(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d_model", "n_heads", "n_layers", "canvas", "s_text", "s_prompt",
-                                         "n_classes", "mask_id", "timesteps", "dtype")] + [("tuning", C.POINTER(Tuning))]
+                                         "n_classes", "mask_id", "timesteps", "dtype", "n_q")] + [("tuning", C.POINTER(Tuning))]
 
 
 _BLOCK_FIELDS = ("norm1_w", "norm1_b", "attn_in_w", "attn_in_b", "attn_out_w", "attn_out_b", "norm2_w", "norm2_b",
@@ -263,7 +263,8 @@ class Schedule:
 def make_shape(cfg, dtype: torch.dtype, tuning: "Tuning | None" = None) -> Shape:
     lib()                                             # TUNING holds the library's defaults from here on
     return Shape(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.canvas, cfg.s_text, cfg.s_prompt, cfg.n_classes,
-                 cfg.mask_id, cfg.timesteps, dtype_code(dtype), C.pointer(tuning if tuning is not None else TUNING))
+                 cfg.mask_id, cfg.timesteps, dtype_code(dtype), getattr(cfg, "n_q", 1),
+                 C.pointer(tuning if tuning is not None else TUNING))
 
 
 class DeviceWeights:
@@ -280,6 +281,8 @@ class DeviceWeights:
             return t.data_ptr()
 
         self.blocks = (BlockWeights * n_layers)()
+        # n_q > 1: resps_emb.weight is [n_q, K, d] and final.{weight, bias} are [n_q * K, d] / [n_q * K], both contiguous -- the
+        # layouts d3pm_weights documents
         names = {"norm1_w": "norm1.weight", "norm1_b": "norm1.bias", "attn_in_w": "attn.in_proj_weight",
                  "attn_in_b": "attn.in_proj_bias", "attn_out_w": "attn.out_proj.weight",
                  "attn_out_b": "attn.out_proj.bias", "norm2_w": "norm2.weight", "norm2_b": "norm2.bias",
@@ -379,6 +382,7 @@ class Sampler:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.shape = make_shape(cfg, dtype)
+        self.n_q = max(1, getattr(cfg, "n_q", 1))       # quantizer levels generated jointly (> 1: this build's extension)
         self.weights = DeviceWeights(tensors, cfg.n_layers)
         self._tensors, self._fp8 = tensors, None
         # fp8 fast path: also run fc2 on MX operands (fc1's GELU epilogue then writes the hidden layer in that format)?  Off: measured
@@ -444,9 +448,10 @@ class Sampler:
 
     def _check_grid(self, x, frame_mask=None, name="x_t"):
         cfg = self.cfg
-        if not isinstance(x, torch.Tensor) or x.dim() != 2:
-            raise D3PMError(f"{name}: expected an int32 [B, {cfg.canvas}] token grid")
-        _require(x, name, (x.shape[0], cfg.canvas), (torch.int32,), self.device)
+        tail = (cfg.canvas,) if self.n_q == 1 else (cfg.canvas, self.n_q)
+        if not isinstance(x, torch.Tensor) or x.dim() != 1 + len(tail):
+            raise D3PMError(f"{name}: expected an int32 [B, {', '.join(map(str, tail))}] token grid")
+        _require(x, name, (x.shape[0],) + tail, (torch.int32,), self.device)
         if x.shape[0] < 1:
             raise D3PMError(f"{name}: empty batch")
         if frame_mask is not None:
@@ -464,7 +469,7 @@ class Sampler:
         B = self._check_grid(x_t, frame_mask)
         self._check_kv(kv_t, kv_p, B)
         ws = self.workspace(B)
-        logits = torch.empty((B, cfg.canvas, cfg.n_classes), dtype=self.dtype, device=self.device) if want_logits else None
+        logits = torch.empty((B, cfg.canvas) + self._lvl() + (cfg.n_classes,), dtype=self.dtype, device=self.device) if want_logits else None
         hidden = torch.empty((B, cfg.canvas, cfg.d_model), dtype=self.dtype, device=self.device) if want_hidden else None
         if fp8:
             check(lib().d3pm_denoise_step_fp8(C.byref(self.shape), C.byref(self.weights.c_struct),
@@ -477,13 +482,16 @@ class Sampler:
                                       _p(hidden), only_layers, flags, stream_ptr()), "d3pm_denoise_step")
         return logits, hidden
 
+    def _lvl(self):
+        return () if self.n_q == 1 else (self.n_q,)
+
     def posterior_sample(self, logits, x_t, t, seed, utt0=0, flags=0, want_posterior=False):
         cfg = self.cfg
         B = self._check_grid(x_t)
         logits = logits.contiguous() if isinstance(logits, torch.Tensor) else logits
-        _require(logits, "logits", (B, cfg.canvas, cfg.n_classes), tuple(_DTYPES), self.device)
+        _require(logits, "logits", (B, cfg.canvas) + self._lvl() + (cfg.n_classes,), tuple(_DTYPES), self.device)
         x_next = torch.empty_like(x_t)
-        post = torch.empty((B, cfg.canvas, cfg.n_classes), dtype=torch.int16, device=self.device) if want_posterior else None
+        post = torch.empty((B, cfg.canvas) + self._lvl() + (cfg.n_classes,), dtype=torch.int16, device=self.device) if want_posterior else None
         check(lib().d3pm_posterior_sample(C.byref(self.shape), B, _p(logits), dtype_code(logits.dtype), _p(x_t),
                                           _p(x_next), int(t), C.byref(self.schedule.c_struct), seed, utt0, flags,
                                           _p(post), stream_ptr()), "d3pm_posterior_sample")
@@ -508,7 +516,7 @@ class Sampler:
         B = self._check_grid(x, frame_mask, "x")
         self._check_kv(kv_t, kv_p, B)
         ws = self.workspace(B, slot)
-        tr = torch.empty((t_start - t_stop, B, cfg.canvas), dtype=torch.int32, device=self.device) if trace else None
+        tr = torch.empty((t_start - t_stop, B, cfg.canvas) + self._lvl(), dtype=torch.int32, device=self.device) if trace else None
         if fp8:
             check(lib().d3pm_sample_loop_fp8(C.byref(self.shape), C.byref(self.weights.c_struct),
                                              C.cast(self.fp8_weights().blocks, C.c_void_p), B, _p(x), _p(frame_mask),

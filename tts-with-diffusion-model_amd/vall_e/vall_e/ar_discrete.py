@@ -132,17 +132,25 @@ class AR(SymmapState, nn.Module):
     num_classes = N_CLASSES
 
     def __init__(self, d_model=512, n_steps=100, n_tokens=1024, max_n_levels=8, n_heads=8, num_layers=6, *,
-                 canvas: int = 448, n_frames: int = 350, s_text: int = 50, s_prompt: int = 398):
+                 canvas: int = 448, n_frames: int = 350, s_text: int = 50, s_prompt: int = 398, n_q: int = 1):
+        """Positional arguments as upstream (ar_discrete.py:205).  `n_q` > 1 is this build's extension (SURVEY.md section 8d
+        config 2, BASELINE.json configs[1] "x 8 quantizers"; upstream generates level 0 only and leaves levels 1..7 to the NAR
+        model): the D3PM then denoises all n_q quantizer levels of a frame jointly -- token grids [B, canvas, n_q], a frame's
+        input = the sum of its level embeddings (`resps_emb.weight` [n_q, K, d]), `final` has n_q * K outputs, and every
+        (frame, level) is sampled like a level-0 token.  n_q = 1 is the upstream model, bit for bit."""
         super().__init__()
         if n_tokens + 1 != N_CLASSES:
             raise ValueError("the absorbing-state tables assume 1024 codec ids + 1 mask id")
+        if not 1 <= n_q <= 16:
+            raise ValueError("n_q must be in 1..16")
         self.cfg = D3PMConfig(d_model=d_model, n_heads=n_heads, n_layers=num_layers, canvas=canvas, n_frames=n_frames,
-                              s_text=s_text, s_prompt=s_prompt, timesteps=n_steps, n_levels=max_n_levels)
+                              s_text=s_text, s_prompt=s_prompt, timesteps=n_steps, n_levels=max_n_levels, n_q=n_q)
+        self.n_resp_levels = n_q
         cfg, d = self.cfg, d_model
         self.timesteps = n_steps                       # read at call time, like upstream (:750)
         self.text_emb = nn.Embedding(N_CLASSES, d, padding_idx=0)
         self.proms_emb = _LevelSumEmbedding(max_n_levels, N_CLASSES, d)
-        self.resps_emb = nn.Embedding(N_CLASSES, d, padding_idx=0)
+        self.resps_emb = nn.Embedding(N_CLASSES, d, padding_idx=0) if n_q == 1 else _LevelSumEmbedding(n_q, N_CLASSES, d)
         self.time_emb = nn.Embedding(n_steps + 1, d)
         self.token_emb = nn.Embedding(N_CLASSES, d)    # unused upstream too; kept for state-dict parity
 
@@ -154,7 +162,7 @@ class AR(SymmapState, nn.Module):
         self.encodertext = encoder(2)
         self.encoder2 = encoder(3)
         self.blocks = nn.ModuleList([_DiTBlockParams(d, n_heads) for _ in range(num_layers)])
-        self.final = nn.Linear(d, N_CLASSES)
+        self.final = nn.Linear(d, n_q * N_CLASSES)
         self._pe_cache = {}
         self.eps = 1.0e-6
         self._sampler = None
@@ -172,7 +180,7 @@ class AR(SymmapState, nn.Module):
     @classmethod
     def from_config(cls, cfg: D3PMConfig) -> "AR":
         return cls(cfg.d_model, cfg.timesteps, cfg.n_classes - 1, cfg.n_levels, cfg.n_heads, cfg.n_layers,
-                   canvas=cfg.canvas, n_frames=cfg.n_frames, s_text=cfg.s_text, s_prompt=cfg.s_prompt)
+                   canvas=cfg.canvas, n_frames=cfg.n_frames, s_text=cfg.s_text, s_prompt=cfg.s_prompt, n_q=cfg.n_q)
 
     @property
     def dtype(self) -> torch.dtype:
@@ -247,9 +255,10 @@ class AR(SymmapState, nn.Module):
         n_frames = cfg.n_frames if n_frames is None else n_frames
         if not 0 < n_frames <= cfg.canvas:
             raise ValueError(f"n_frames must be in 1..{cfg.canvas}")
-        x = torch.zeros((batch, cfg.canvas), dtype=torch.int32, device=self.device)
+        shape = (batch, cfg.canvas) if cfg.n_q == 1 else (batch, cfg.canvas, cfg.n_q)
+        x = torch.zeros(shape, dtype=torch.int32, device=self.device)
         x[:, :n_frames] = MASK_ID
-        frame_mask = (x[0] != 0).to(torch.uint8)
+        frame_mask = (x[0].reshape(cfg.canvas, -1)[:, 0] != 0).to(torch.uint8)
         return x, frame_mask
 
     # ------------------------------------------------------------------ the hot path
@@ -260,7 +269,8 @@ class AR(SymmapState, nn.Module):
                        graph: Optional[bool] = None, fp8: bool = False):
         """Reverse diffusion for len(text_list) utterances.  Positional behaviour as upstream:
         one utterance -> int64 [canvas] (squeezed, untrimmed; rows >= n_frames are sampled from
-        final.bias and meaningless).  `resps_list` is ignored, as upstream ignores it (:699).
+        final.bias and meaningless); with n_q > 1 (constructor) [canvas, n_q] / [B, canvas, n_q].  `resps_list` is ignored, as
+        upstream ignores it (:699).
         `fp8=True` is the fast configuration of BASELINE.json configs[4]: the QKV, cross-attention query, fc1 and fc2
         projections run on the block-scaled fp8 matrix instruction (e4m3 codes, one power-of-two scale per 32 elements;
         d_model = 512, 16-bit model, batch * canvas a multiple of 192); the reference has no such mode.

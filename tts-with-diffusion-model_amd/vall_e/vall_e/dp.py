@@ -24,7 +24,8 @@ def shard_bounds(n_items: int, world: int, rank: int) -> tuple[int, int]:
 
 def generate_audio_dp(model, text_list: Sequence[torch.Tensor], proms_list: Sequence[torch.Tensor], *, seed: int,
                       group=None, generate_fn: Optional[Callable] = None, **kw) -> torch.Tensor:
-    """Every rank passes the same global lists and gets back the same int64 [B, canvas] grid."""
+    """Every rank passes the same global lists and gets back the same int64 [B, canvas] grid ([B, canvas, n_q] for a model
+    built with n_q > 1)."""
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     B = len(text_list)
@@ -35,9 +36,11 @@ def generate_audio_dp(model, text_list: Sequence[torch.Tensor], proms_list: Sequ
         local = local.reshape(hi - lo, -1).to(torch.int32)
     else:
         local = None
+    n_q = max(1, getattr(model.cfg, "n_q", 1))
+    shape = (-1, model.cfg.canvas) if n_q == 1 else (-1, model.cfg.canvas, n_q)
     if world == 1:
-        return local.long()
-    canvas = model.cfg.canvas
+        return local.long().reshape(shape)
+    canvas = model.cfg.canvas * n_q
     dev = local.device if local is not None else model.device
     per = -(-B // world)                                   # padded shard so one fixed-size all-gather suffices
     send = torch.zeros((per, canvas), dtype=torch.int32, device=dev)
@@ -49,7 +52,7 @@ def generate_audio_dp(model, text_list: Sequence[torch.Tensor], proms_list: Sequ
     for r in range(world):
         a, b = shard_bounds(B, world, r)
         parts.append(recv[r * per: r * per + (b - a)])
-    return torch.cat(parts).long()
+    return torch.cat(parts).long().reshape(shape)
 
 
 def generate_codes_dp(ar, nar, text_list: Sequence[torch.Tensor], proms_list: Sequence[torch.Tensor], *, seed: int,

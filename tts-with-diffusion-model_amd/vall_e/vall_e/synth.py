@@ -35,6 +35,8 @@ class D3PMConfig:
     cond_layers: int = 2
     n_classes: int = N_CLASSES
     mask_id: int = MASK_ID
+    n_q: int = 1               # quantizer levels the D3PM generates jointly; 1 = upstream (level 0 only).  > 1: this build's
+                               # extension: [n_q] level embeddings summed in, n_q x K logits out
 
     @property
     def head_dim(self) -> int:
@@ -53,6 +55,11 @@ class D3PMConfig:
                           s_text=50, s_prompt=225)
 
     @staticmethod
+    def libritts_8q() -> "D3PMConfig":
+        """The n_q = 8 extension of the LibriTTS config (BASELINE.json configs[1] "750 codec frames x 8 quantizers")."""
+        return dataclasses.replace(D3PMConfig.libritts(), n_q=8)
+
+    @staticmethod
     def vctk_long_prompt() -> "D3PMConfig":
         """10 s prompt, 5 s target, 200-step schedule."""
         return D3PMConfig(d_model=512, n_heads=8, n_layers=6, canvas=384, n_frames=375,
@@ -65,11 +72,11 @@ def state_dict_spec(cfg: D3PMConfig) -> dict[str, tuple[int, ...]]:
     spec: dict[str, tuple[int, ...]] = {
         "text_emb.weight": (K, d),
         "proms_emb.weight": (cfg.n_levels, K, d),
-        "resps_emb.weight": (K, d),
+        "resps_emb.weight": (K, d) if cfg.n_q == 1 else (cfg.n_q, K, d),
         "time_emb.weight": (cfg.timesteps + 1, d),
         "token_emb.weight": (K, d),            # present in the reference state dict, never used
-        "final.weight": (K, d),
-        "final.bias": (K,),
+        "final.weight": (cfg.n_q * K, d),
+        "final.bias": (cfg.n_q * K,),
     }
 
     def mha(prefix):
@@ -119,7 +126,7 @@ def make_state_dict(cfg: D3PMConfig, seed: int = 0, logit_gain: float = 1.0) -> 
         leaf = key.rsplit(".", 1)[-1]
         if key.endswith("_emb.weight"):
             w = rng.standard_normal(shape)
-            if key in ("text_emb.weight", "resps_emb.weight"):
+            if key == "text_emb.weight" or (key == "resps_emb.weight" and cfg.n_q == 1):
                 w[0] = 0.0                      # nn.Embedding(padding_idx=0) (ar_discrete.py:210,212)
         elif ".norm" in key:
             w = (1.0 if leaf == "weight" else 0.0) + 0.1 * rng.standard_normal(shape)
