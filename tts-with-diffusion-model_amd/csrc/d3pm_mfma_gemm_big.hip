@@ -581,7 +581,16 @@ int big_linear_tile(int dtype, const LinearArgs& a, int want) {
   if (gelu && !(dtype == D3PM_BF16 && gelu_table_enabled()) && fits(3, false)) return 3;   // bf16: table lookup, cheap enough for one WG per CU
   if (fits(2, false)) return 2;
   if (fits(3, false)) return 3;
-  return fits(1, false) ? 1 : 0;
+  if (fits(1, false)) return 1;
+  // Mid-size batches (the VCTK config: 32 x 384 rows; 8 .. 16 utterances of the libritts shape) leave the chip partly idle with
+  // every big tile, yet 192 x 128 tiles of four waves still beat the 128 x 128 kernels there once at least half (long K) or all
+  // of the CUs get one: measured at M = 12288 / 6144 (tests/ab_gemm_shapes.py, profiles/round3_f_ab_gemm_shapes.txt): qkv 24.1 vs
+  // 26.6 / 15.6 vs 17.2 us, out-projection 12.8 vs 15.8 us, fc2 31.8 vs 39.0 / 29.5 vs 35.4 us
+  if (a.M % 192 == 0 && a.N % 128 == 0) {
+    const long long tiles = static_cast<long long>(a.M / 192) * (a.N / 128);
+    if (tiles >= (a.K >= 1024 ? 128 : 256)) return 3;
+  }
+  return 0;
 }
 
 // kernel MODE template argument: 1 = the shipped schedule (hand-placed reads); every other value is an experiment that
