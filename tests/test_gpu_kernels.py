@@ -331,10 +331,21 @@ def test_linear_mx_against_fp32_on_the_same_codes(built_lib, dtype, M, N, K, epi
         ref = ref * mask.float().repeat(M // T)[:, None]
     assert_close_lp(y, ref, dtype, f"mx linear {M}x{N}x{K} {epi}")
     if epi in ("bias", "gelu", "nobias"):
-        # the MX-output epilogue (fc1 -> fc2) quantises exactly the 16-bit value the plain epilogue stores
+        # the MX-output epilogue (fc1 -> fc2): fp32 -> e4m3 directly (no 16-bit rounding in between) and the tanh form of GELU
+        # (|gelu_tanh - gelu_erf| < 5e-4): every element within the e4m3 grid of the fp32 reference -- half a step of 2^-3
+        # relative, 2^-9 of the block maximum for the subnormal range -- plus that slack; block scales = the rule on the block's
+        # own maximum (a maximum on the edge of a power of two may land on either side: one exponent step allowed)
         y8, sy = _hip.op_linear_mx(x8, sx, w8, sw, b, dtype, act=1 if epi == "gelu" else 0, mx_out=True)
-        r8, rs = _hip.quantize_mx(y)
-        assert torch.equal(sy, rs) and torch.equal(y8, r8)
+        ref32 = _hip.dequantize_mx(x8, sx) @ _hip.dequantize_mx(w8, sw).T + (b.float() if b is not None else 0)
+        if epi == "gelu":
+            ref32 = torch.nn.functional.gelu(ref32)
+        deq = _hip.dequantize_mx(y8, sy)
+        bm = ref32.abs().reshape(M, N // 32, 32).amax(dim=-1)
+        tol = 0.0625 * ref32.abs() + (2.0 ** -9 * 1.01) * bm.repeat_interleave(32, dim=1) + 1e-3
+        assert ((deq - ref32).abs() <= tol).all(), f"{((deq - ref32).abs() - tol).max().item()}"
+        rs = _hip.mx_scale_bytes(bm).reshape(M, N // 128, 4).permute(0, 2, 1)
+        assert ((sy.int() - rs.int()).abs() <= 1).all() and (sy == rs).float().mean().item() > 0.98
+        assert (y8 & 0x7F).max().item() <= 0x7E
 
 
 def test_linear_mx_rejects_what_it_cannot_run(built_lib):

@@ -119,6 +119,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   const int lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, cnt = tq + (xcd < tr ? 1 : 0);
   int t = blockIdx.x >> 3;
   if (t >= cnt) return;                                              // block-uniform
+  if constexpr ((MODE & (8192 | 16384)) != 0) {
+    // A/B: de-synchronise the chip-wide output burst -- the workgroups of every second XCD start later by a fraction of a tile
+    // (bits 13 / 14 / both: ~2 / 4 / 6 us; one s_sleep 127 measured ~3.1 us), so that one group's stores drain while the other
+    // group streams operands
+    if (xcd & 1) {
+      constexpr int units = ((MODE >> 13) & 3) * 2;
+      for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(40);          // ~1 us each
+    }
+  }
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
   // DMA piece j of an operand tile = rows 8j .. 8j+7; a wave takes pieces j = wave + NW p, so the swizzle key
   // (row >> 1) & 7 = (4 (j & 1) + (lane >> 4)) & 7 is the same for all of its pieces: one per-lane offset per operand
@@ -662,6 +671,11 @@ static int big_launch_geometry(int id, const LinearArgs& a, int n_tiles, int til
   if (md == 33 && E == 0 && id == 2) return big_launch<U, 0, 2, 4, 33>(a, n_tiles, tiles_total, grid, lds, s);       // its LDS-DMA twin
   if (md == 2049 && E == 0) {      // A/B: all DMA pieces of a k-step issued at its top (tests/ab_gemm.py), plain epilogue only
     if (id == 2) return big_launch<U, 0, 2, 4, 2049>(a, n_tiles, tiles_total, grid, lds, s);
+  }
+  if (md == 8193 || md == 16385 || md == 24577) {      // staggered XCD groups (A/B: tests/ab_gemm.py), 192 x 256 and plain / R1 epilogues only
+    if (id == 2 && md == 8193) return big_launch<U, E, 2, 4, 8193>(a, n_tiles, tiles_total, grid, lds, s);
+    if (id == 2 && md == 16385) return big_launch<U, E, 2, 4, 16385>(a, n_tiles, tiles_total, grid, lds, s);
+    if (id == 2 && md == 24577) return big_launch<U, E, 2, 4, 24577>(a, n_tiles, tiles_total, grid, lds, s);
   }
   if (md == 513) {      // hand-placed schedule with non-temporal output stores (A/B: tests/ab_gemm.py)
     if (id == 1) return big_launch<U, E, 1, 8, 513>(a, n_tiles, tiles_total, grid, lds, s);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void quantize_mx_rows(const T* __restrict__ x,
 // k-step's 48) for twice the contraction depth, so a projection needs half the k-steps, DMA pieces and barriers.
 // OUT8 (fc1 -> fc2): the epilogue quantises its own output -- a lane group of four owns 32 consecutive columns of a row after
 // the regrouping of epilogue_store, exactly one MX block -- and writes codes + block scales instead of 16-bit values: the
-// consumer's operand format, no row-wide reduction, half the output bytes.
+// consumer's operand format, no row-wide reduction, half the output bytes (fp32 -> e4m3 directly, tanh-form GELU: see the epilogue).
 template <typename T, int EPI, int WM, int WN, bool OUT8>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mx_big(const uint8_t* __restrict__ X, int ldx, const uint8_t* __restrict__ SX,
                                                               const uint8_t* __restrict__ W, const uint8_t* __restrict__ SW,
@@ -293,23 +293,40 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mx_big(const uint8_t* __
       step(I1{}, I3{}, I0{}, last ? sx_next : sx + k0 + 512, last ? sw_next : sw + k0 + 512, nwb, nxb);
     }
     if constexpr (OUT8) {
-      // epilogue with an MX output: bias + activation as the 16-bit epilogue (the 16-bit rounding included: the value that is
-      // quantised is the one the 16-bit path would have stored), then per (row, 32 columns) block: absmax over the four lanes
-      // that own it, scale byte, eight codes per lane.  Column pair np of this wave = block (wn * 2 + np) % 4 of k-step
-      // (n0 + wn * 64) / 128 of the consumer's K = N.
-      uintx4 packed[12];
-      epilogue_store<T, EPI, 4, 6, true, true>(acc, bias, Y, ldy, nullptr, nullptr, ldr, nullptr, 1, M, N, m0 + wm * 96, n0 + wn * 64, lane, packed);
-      const int nks = N / 128, col0 = n0 + wn * 64;
+      // epilogue with an MX output (the hidden layer between fc1 and fc2): bias + activation in fp32, then per (row, 32 columns)
+      // block: absmax over the four lanes that own it, scale byte, eight codes per lane.  The values go from fp32 straight to e4m3
+      // -- no 16-bit rounding in between, it would be noise below the 3 mantissa bits that survive -- and GELU takes its tanh form
+      //     gelu(v) ~ v / (1 + 2^(-2 log2(e) sqrt(2/pi) (v + 0.044715 v^3)))        (|error| < 5e-4 absolute, e4m3 keeps 6e-2 relative)
+      // two transcendentals and four FMAs instead of the 16-instruction exact-erf chain of the 16-bit epilogue: this epilogue is
+      // what the launch waits for once the matrix work takes half the time (profiles/round3_d_ab_mx_fp8_gemm.txt).
+      // Column pair np of this wave = block (wn * 2 + np) % 4 of k-step (n0 + wn * 64) / 128 of the consumer's K = N.
+      const int g = lane >> 4, nks = N / 128, col0 = n0 + wn * 64;
+      float bv[4][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        Pack4<T> pb{};
+        if (bias) pb = *reinterpret_cast<const Pack4<T>*>(bias + col0 + nt * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[nt][r] = bias ? static_cast<float>(pb.v[r]) : 0.f;
+      }
 #pragma unroll
       for (int mt = 0; mt < 6; ++mt) {
         uint2 cd[2];
         uint32_t sb[2];
 #pragma unroll
         for (int np = 0; np < 2; ++np) {
-          const Pack8<T> p = __builtin_bit_cast(Pack8<T>, packed[mt * 2 + np]);
           float v[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(p.v[i]);
+          for (int r = 0; r < 8; ++r) {
+            float x = acc[2 * np + (r >> 2)][mt][r & 3] + bv[2 * np + (r >> 2)][r & 3];
+            if constexpr ((EPI & EPI_GELU) != 0) {
+              const float u = x * __builtin_fmaf(x * x, -2.302208198f * 0.044715f, -2.302208198f);      // -2 log2(e) sqrt(2/pi) (x + 0.044715 x^3)
+              x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+            }
+            v[r] = x;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) swap_rows16(v[r], v[4 + r]);      // lane: 8 consecutive columns at 32 np + nq (d3pm_mfma_tile.h)
           cd[np] = mx_block_quantise(v, sb[np]);
         }
         const int row = m0 + wm * 96 + mt * 16 + (lane & 15);
