@@ -140,3 +140,28 @@ print('RCCL_OK', torch.cuda.nccl.version())
                MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(768, 512, 2048), (200, 1025, 77), (64, 64, 16), (130, 96, 513)])
+def test_matmul_f32_on_the_matrix_pipe_has_the_bits_of_the_fma_chain(ta, tb, M, N, K):
+    """d3pm_op_matmul_f32 takes v_mfma_f32_32x32x2_f32 for products of at least 64 x 64 outputs (the dX / dW products of every
+    nn.Linear in the backward pass): that instruction is a k-ordered fp32 fmaf chain, so the result must equal -- bit for bit --
+    what the 32 x 32 FMA-tile kernel computes for the same rows, which is how products narrower than 64 columns still run
+    (the same product cut into 32-column strips).  All four transposition combinations, ragged shapes, beta, row mask."""
+    from vall_e.vall_e import train as T
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(DEV)
+    b = torch.randn((N, K) if tb else (K, N), generator=g).to(DEV)
+    c0 = torch.randn(M, N, generator=g).to(DEV)
+    mask = (torch.rand(50, generator=g) < 0.8).to(torch.uint8).to(DEV)
+    out = T.matmul(a, b, c0.clone(), ta=ta, tb=tb, beta=0.5, row_mask=mask, period=50)
+    strips = c0.clone()
+    for j in range(0, N, 32):                                            # < 64 columns: the FMA-tile kernel
+        bj = (b[j:j + 32] if tb else b[:, j:j + 32])
+        T.matmul(a, bj, strips[:, j:j + 32], ta=ta, tb=tb, beta=0.5, row_mask=mask, period=50)
+    assert torch.equal(out, strips), f"{(out != strips).float().mean().item():.2e} of the elements differ"
+    A = (a.t() if ta else a).double()
+    B = (b.t() if tb else b).double()
+    ref = (A @ B) * mask.double().repeat(M // 50 + 1)[:M, None] + 0.5 * c0.double()
+    assert (out.double() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())

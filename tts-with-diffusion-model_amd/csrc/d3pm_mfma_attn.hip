@@ -434,7 +434,13 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <typename T>
+// PIPE: software-pipelined walk -- the S^T = K . Q^T products of tile i + 1 are issued BEFORE the softmax of tile i (a second
+// set of score registers), so the matrix pipe works under the exponentials of the same wave instead of waiting for them: with
+// every K / V tile resident a wave's time per tile is its own dependency chain (LDS reads -> 16 MFMAs -> max -> 32 v_exp ->
+// V reads -> 20 MFMAs), which two waves per SIMD do not cover.  Exactness: the prefetched product starts from the -m_ref of the
+// moment; when the softmax of tile i then moves m_ref (always on the first tile, otherwise only if a score exceeds it by 2^8)
+// the product of tile i + 1 is issued again from the new -m_ref, so every number is the one the plain walk computes.
+template <typename T, bool PIPE = false>
 __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ Q1, const T* __restrict__ K1, const T* __restrict__ V1,
                                                           T* __restrict__ O1, int S1, const T* __restrict__ Q2,
                                                           const T* __restrict__ K2, const T* __restrict__ V2, T* __restrict__ O2,
@@ -522,10 +528,9 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) acc_o[qg][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int tile = 0; tile < nt; ++tile) {
+    // S^T of one tile from the current -m_ref
+    auto qk_tile = [&](int tile, floatx4 (&s)[QG][4]) __attribute__((always_inline)) {
       const char* kb = smem + (t0 + tile) * 2 * TILE;
-      const char* vb = kb + TILE;
-      floatx4 s[QG][4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -534,9 +539,12 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
 #pragma unroll
           for (int qg = 0; qg < QG; ++qg) s[qg][kt] = mma<T>(kf, qf[qg][ks], ks == 0 ? negm[qg] : s[qg][kt]);
         }
+    };
+    // softmax of one tile's scores -> the 16-bit probabilities as PV operands; returns whether m_ref moved (wave-uniform)
+    auto softmax_tile = [&](int tile, floatx4 (&s)[QG][4], uint4 (&pf)[QG][2]) __attribute__((always_inline)) -> bool {
       const bool ragged = (tile == nt - 1) && (S & (BKV - 1));
       const int key_base = tile * BKV + 4 * g;
-      uint4 pf[QG][2];
+      bool moved = false;
 #pragma unroll
       for (int qg = 0; qg < QG; ++qg) {
         if (ragged) {
@@ -553,6 +561,7 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
           mx = fmaxf(fmaxf(mx, s[qg][kt][2]), s[qg][kt][3]);
         }
         if (tile == 0 || __any(mx > kDefer)) {
+          moved = true;
           mx = max_over_query_lanes(mx);
           const float delta = tile == 0 ? mx : fmaxf(mx, 0.f);
 #pragma unroll
@@ -581,6 +590,10 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
           pf[qg][kb2] = uint4{pack2<T>(pa[0], pa[1]), pack2<T>(pa[2], pa[3]), pack2<T>(pb[0], pb[1]), pack2<T>(pb[2], pb[3])};
         }
       }
+      return moved;
+    };
+    auto pv_tile = [&](int tile, const uint4 (&pf)[QG][2]) __attribute__((always_inline)) {
+      const char* vb = smem + (t0 + tile) * 2 * TILE + TILE;
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
@@ -599,6 +612,31 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) acc_l[qg] = mma<T>(ones, pf[qg][kb2], acc_l[qg]);
+    };
+    if constexpr (PIPE) {
+      floatx4 sa[QG][4], sb[QG][4];
+      uint4 pf[QG][2];
+      auto walk = [&](int tile, floatx4 (&cur)[QG][4], floatx4 (&nxt)[QG][4]) __attribute__((always_inline)) {
+        const bool more = tile + 1 < nt;
+        if (more && tile > 0) qk_tile(tile + 1, nxt);       // ahead of the exponentials of `tile` (the first tile always moves m_ref)
+        const bool moved = softmax_tile(tile, cur, pf);
+        if (more && (tile == 0 || moved)) qk_tile(tile + 1, nxt);       // m_ref moved: the product (again) from the new -m_ref
+        pv_tile(tile, pf);
+      };
+      qk_tile(0, sa);
+      for (int tile = 0; tile < nt; tile += 2) {           // two tiles per trip: the score sets trade places without copies
+        walk(tile, sa, sb);
+        if (tile + 1 >= nt) break;
+        walk(tile + 1, sb, sa);
+      }
+    } else {
+      for (int tile = 0; tile < nt; ++tile) {
+        floatx4 s[QG][4];
+        uint4 pf[QG][2];
+        qk_tile(tile, s);
+        softmax_tile(tile, s, pf);
+        pv_tile(tile, pf);
+      }
     }
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
@@ -643,7 +681,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
   const d3pm_tuning& tn = tune_of(a.tune);
   const int g_attn_cross_resident = tn.attn_cross_resident, g_attn_pair_seq = tn.attn_pair_sequential;
 #ifdef D3PM_ABLATIONS
-  const int g_attn_qg = ab_knobs().attn_arm ? ab_knobs().attn_arm : tn.attn_query_groups;      // arms >= 3: include/d3pm_hip_ab.h
+  const int g_attn_qg = (ab_knobs().attn_arm && ab_knobs().attn_arm < 300) ? ab_knobs().attn_arm : tn.attn_query_groups;      // arms >= 3: include/d3pm_hip_ab.h
 #else
   const int g_attn_qg = (tn.attn_query_groups == 1 || tn.attn_query_groups == 2) ? tn.attn_query_groups : 0;
 #endif
@@ -656,19 +694,24 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     if (g_attn_cross_resident == 3) n_qsplit = n_qblocks;              // tuning: one query block per workgroup (the first form)
     const dim3 grid(static_cast<unsigned>(n_qsplit * a.H * a.B)), block(512);
     const size_t lds = static_cast<size_t>(1 + (a.S2 + BKV - 1) / BKV) * 2 * TILE;
-#define D3PM_CROSS(T)                                                                                                        \
+#define D3PM_CROSS(T, PIPE)                                                                                                  \
     do {                                                                                                                     \
       static bool attr_set = false;                                                                                          \
       if (!attr_set) {                                                                                                       \
-        D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_cross_hd64<T>),                               \
+        D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_cross_hd64<T, PIPE>),                         \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 2 * TILE));                       \
         attr_set = true;                                                                                                     \
       }                                                                                                                      \
-      attn_cross_hd64<T><<<grid, block, lds, s>>>(static_cast<const T*>(a.Q), static_cast<const T*>(a.K),                     \
+      attn_cross_hd64<T, PIPE><<<grid, block, lds, s>>>(static_cast<const T*>(a.Q), static_cast<const T*>(a.K),               \
           static_cast<const T*>(a.V), static_cast<T*>(a.O), a.S, static_cast<const T*>(a.Q2), static_cast<const T*>(a.K2),    \
           static_cast<const T*>(a.V2), static_cast<T*>(a.O2), a.S2, a.ldq, a.ldkv, a.ldo, a.Tq, a.scale, a.H, n_qblocks, n_qsplit); \
     } while (0)
-    if (dtype == D3PM_F16) D3PM_CROSS(f16); else D3PM_CROSS(bf16);
+#ifdef D3PM_ABLATIONS
+    if (ab_knobs().attn_arm == 300) {      // A/B: the software-pipelined walk
+      if (dtype == D3PM_F16) D3PM_CROSS(f16, true); else D3PM_CROSS(bf16, true);
+    } else
+#endif
+    if (dtype == D3PM_F16) D3PM_CROSS(f16, false); else D3PM_CROSS(bf16, false);
 #undef D3PM_CROSS
     D3PM_LAUNCH_CHECK();
     return D3PM_OK;

@@ -8,8 +8,8 @@
 // reduction is one bucketed torch.distributed all-reduce (RCCL) of the flat gradient.
 //
 // Scope: fp32 tensors (the F32 precision mode: the gradient check is against torch.autograd over the oracle in fp32),
-// generic FMA kernels sized for clarity, not for the MFMA roofline -- the sampler is this build's hot path, training is
-// a "next" row.  Every kernel accumulates in fp32 in a fixed order except the per-column reductions that use fp32 atomics
+// generic kernels sized for clarity -- the sampler is this build's hot path, training is a "next" row -- except the matrix
+// products (dX = dY W, dW += dY^T X of every nn.Linear), which run on the fp32 matrix instruction with unchanged bits.  Every kernel accumulates in fp32 in a fixed order except the per-column reductions that use fp32 atomics
 // (LayerNorm / embedding gradients), which are order-independent to rounding.
 #include <cmath>
 
@@ -57,6 +57,74 @@ __global__ __launch_bounds__(256) void matmul_strided(const float* __restrict__ 
         *c = beta == 0.f ? v : fmaf(beta, *c, v);
       }
     }
+}
+
+// The same product on the matrix pipe: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate) is bit for bit a k-ordered fmaf
+// chain (MI355X_MICROARCH.md "FP32-input MFMA"), i.e. exactly the chain of matmul_strided above -- same gradients to the last
+// bit, at the fp32 matrix rate (157 TFLOP/s peak) instead of one FMA per lane and LDS read.  128 x 128 tile per 256 threads
+// (wave = 64 x 64 = 2 x 2 MFMA tiles), k-step 16 through LDS ([k][row] images, padded: the fragment of a lane is ONE float --
+// A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]); the global reads walk whichever operand index is
+// contiguous in memory (all four transposition combinations arrive through the strides).
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void matmul_strided_mfma(const float* __restrict__ A, long sai, long sak, const float* __restrict__ B,
+                                                           long sbk, long sbj, float* C, int ldc, int M, int N, int K, float beta,
+                                                           const uint8_t* __restrict__ row_mask, int mask_period) {
+  constexpr int TM = 128, TN = 128, BKS = 16, LD = 132;          // LD: 128 + 4 floats of padding (conflict-free b32 reads and writes)
+  __shared__ float sa[BKS][LD], sb[BKS][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
+  const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+  const int fr = lane & 31, fk = lane >> 5;
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const bool a_k_contig = sak == 1, b_k_contig = sbk == 1;
+  for (int k0 = 0; k0 < K; k0 += BKS) {
+#pragma unroll
+    for (int q = 0; q < (BKS * TM) / 256; ++q) {
+      const int e = tid + 256 * q;
+      {
+        const int kk = a_k_contig ? (e & 15) : (e >> 7), r = a_k_contig ? (e >> 4) : (e & 127);
+        const int i = i0 + r, k = k0 + kk;
+        sa[kk][r] = (i < M && k < K) ? A[i * sai + k * sak] : 0.f;
+      }
+      {
+        const int kk = b_k_contig ? (e & 15) : (e >> 7), r = b_k_contig ? (e >> 4) : (e & 127);
+        const int j = j0 + r, k = k0 + kk;
+        sb[kk][r] = (j < N && k < K) ? B[k * sbk + j * sbj] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < BKS / 2; ++k2) {
+      const float a0 = sa[2 * k2 + fk][wi + fr], a1 = sa[2 * k2 + fk][wi + 32 + fr];
+      const float b0 = sb[2 * k2 + fk][wj + fr], b1 = sb[2 * k2 + fk][wj + 32 + fr];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D of the 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, j = j0 + wj + b * 32 + fr;
+        if (i < M && j < N) {
+          float v = acc[a][b][r];
+          if (row_mask) v *= row_mask[i % mask_period] ? 1.f : 0.f;
+          float* c = C + static_cast<size_t>(i) * ldc + j;
+          *c = beta == 0.f ? v : fmaf(beta, *c, v);
+        }
+      }
 }
 
 // out[j] = beta * out[j] + sum_i X[i][j]
@@ -288,9 +356,15 @@ extern "C" {
 int d3pm_op_matmul_f32(const float* A, long sai, long sak, const float* B, long sbk, long sbj, float* C, int ldc, int M, int N, int K,
                        float beta, const uint8_t* row_mask, int mask_period, void* stream) {
   D3PM_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N, D3PM_E_ARG, "d3pm_op_matmul_f32: bad arguments");
-  dim3 grid((N + 31) / 32, (M + 31) / 32);
-  matmul_strided<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(A, sai, sak, B, sbk, sbj, C, ldc, M, N, K, beta, row_mask,
-                                                                     mask_period > 0 ? mask_period : 1);
+  if (M >= 64 && N >= 64) {      // the matrix-pipe form (same bits); small products keep the 32 x 32 FMA tiles
+    dim3 grid((N + 127) / 128, (M + 127) / 128);
+    matmul_strided_mfma<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(A, sai, sak, B, sbk, sbj, C, ldc, M, N, K, beta, row_mask,
+                                                                            mask_period > 0 ? mask_period : 1);
+  } else {
+    dim3 grid((N + 31) / 32, (M + 31) / 32);
+    matmul_strided<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(A, sai, sak, B, sbk, sbj, C, ldc, M, N, K, beta, row_mask,
+                                                                       mask_period > 0 ? mask_period : 1);
+  }
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;
 }
