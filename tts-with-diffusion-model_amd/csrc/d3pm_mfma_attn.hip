@@ -494,10 +494,11 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
       for (int ks = 0; ks < 2; ++ks) qraw[qg][ks] = *reinterpret_cast<const uint4*>(qp + ks * 32 + g * 8);
     }
   };
-  fetch_q(qs, 0);
+  if constexpr (!PIPE) fetch_q(qs, 0);
   for (int qb = qs; qb < n_qblocks; qb += n_qsplit) {
   const int q0 = (qb * 8 + wave) * (16 * QG);
   for (int prob = 0; prob < 2; ++prob) {
+    if constexpr (PIPE) fetch_q(qb, prob);       // the pipelined walk spends its registers on the second score set: no query prefetch
     T* O = prob == 0 ? O1 : O2;
     const int S = prob == 0 ? S1 : S2, t0 = prob == 0 ? 0 : 1, nt = prob == 0 ? 1 : nt2;
     uint4 qf[QG][2];
@@ -512,8 +513,10 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
                            pack2<T>(static_cast<float>(e[4]) * qscale, static_cast<float>(e[5]) * qscale),
                            pack2<T>(static_cast<float>(e[6]) * qscale, static_cast<float>(e[7]) * qscale)};
       }
-    if (prob == 0) fetch_q(qb, 1);
-    else if (qb + n_qsplit < n_qblocks) fetch_q(qb + n_qsplit, 0);
+    if constexpr (!PIPE) {
+      if (prob == 0) fetch_q(qb, 1);
+      else if (qb + n_qsplit < n_qblocks) fetch_q(qb + n_qsplit, 0);
+    }
     if (!landed) {                                           // one wait for the whole workgroup's K / V image
       __syncthreads();                                       // (drains this wave's DMA pieces, then the barrier)
       landed = true;
