@@ -901,13 +901,18 @@ def prof_enable(kclass: int, max_events: int):
 
 
 def prof_read():
+    if not TUNING.prof:
+        return 0, 0.0, 0.0, 0.0
     n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
     check(lib().d3pm_prof_read(TUNING.prof, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "d3pm_prof_read")
     return n.value, ms.value, fl.value, by.value
 
 
 def prof_read_class(kclass: int):
-    """(launches, total ms, algorithmic flops, algorithmic bytes) of one kernel class; does not reset."""
+    """(launches, total ms, algorithmic flops, algorithmic bytes) of one kernel class; does not reset.  Zeros when no
+    profiler is attached (bench.py --no-kernel-events)."""
+    if not TUNING.prof:
+        return 0, 0.0, 0.0, 0.0
     n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
     check(lib().d3pm_prof_read_class(TUNING.prof, kclass, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "d3pm_prof_read_class")
     return n.value, ms.value, fl.value, by.value
