@@ -79,8 +79,12 @@ enum {
  *   gemm_persist_slots resident workgroups of the persistent 128 x 128 schedule, a multiple of 8 (default 1024 = 4 per CU).
  *   lat_tile           tile of the latency GEMM: 0 = auto (fewest rounds over the 256 CUs, then most workgroups),
  *                      1 / 2 / 3 = always 64 x 64 / 96 x 64 / 32 x 64.
- *   attn_query_groups  16-query groups per wave of the MFMA attention: 0 = auto (2 when that still gives >= 4 workgroups
- *                      per CU, else 1), 1 or 2.
+ *   attn_query_groups  schedule of the MFMA self-attention: 0 = auto -- the software-pipelined 32 x 32 x 16 kernel (one 32-query
+ *                      group per wave, three workgroups per CU) for whole 128-query blocks and 64-key tiles once that grid has two
+ *                      workgroups per CU, else the 16 x 16 x 32 kernel with 2 sixteen-query groups per wave when that still gives
+ *                      >= 4 workgroups per CU, else 1; 1 or 2 = the 16 x 16 x 32 kernel with that many groups; 32 = the 32 x 32 x 16
+ *                      kernel wherever it applies; 33 = as 32 without the software pipeline.  (The two instruction shapes
+ *                      accumulate in different orders: results agree to rounding noise, not bit for bit.)
  *   attn_pair_sequential  a paired attention launch (text + prompt cross-attention) on the tile-by-tile kernel: 2 = every
  *                      workgroup runs both problems one after the other; 0 = the second half of the grid takes problem 2;
  *                      1 (default) = auto: sequential while that still leaves >= 2 workgroups per CU.

@@ -59,6 +59,12 @@ int d3pm_op_final_sample(const d3pm_shape *shape, const d3pm_weights *w, int bat
  * (MI355X_MICROARCH.md "DVFS give-back" item 6).  No output of the kernel depends on it. */
 int d3pm_debug_gemm_clock(unsigned long long *clocks_and_ticks);
 
+/* Shader-clock stamps of the 32 x 32 x 16 self-attention kernel launched under D3PM_AB_ATTN_ARM = 320 with attn_query_groups = 32
+ * (d3pm_mfma_attn32.hip): out[(slot * 12 + tile) * 8 + point], slot 0 = the first workgroup, 1 = one in the middle of the grid,
+ * wave 0 of each; points: 0 top of the tile, 1 next tile's global loads issued, 2 scores available, 3 softmax done,
+ * 4 P.V issued, 5 global loads returned, 6 LDS stores issued, 7 barrier passed. */
+int d3pm_debug_attn32_stamps(unsigned long long *out, int n);
+
 #ifdef __cplusplus
 }
 #endif

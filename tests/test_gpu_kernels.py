@@ -53,7 +53,7 @@ def gemm_variant(request, built_lib):
     _hip.set_gemm_variant(0)
 
 
-@pytest.fixture(params=[1, 2], ids=lambda v: f"qg{v}")
+@pytest.fixture(params=[1, 2, 32, 33], ids=lambda v: f"qg{v}")      # 32 / 33: the 32 x 32 x 16 kernel (pipelined / plain) where it applies
 def attn_qg(request, built_lib):
     from vall_e.vall_e import _hip
     _hip.set_attn_query_groups(request.param)
@@ -205,7 +205,7 @@ def torch_attention(q, k, v, H, scale):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("Tq,S", [(448, 448), (448, 50), (448, 398), (768, 768), (768, 225), (128, 1), (64, 65)])
+@pytest.mark.parametrize("Tq,S", [(448, 448), (448, 50), (448, 398), (768, 768), (768, 225), (128, 1), (64, 65), (384, 384), (128, 64)])
 def test_attention_mfma_vs_generic_vs_torch(attn_qg, dtype, Tq, S):
     from vall_e.vall_e import _hip
     B, H, hd = 2, 8, 64
@@ -221,6 +221,35 @@ def test_attention_mfma_vs_generic_vs_torch(attn_qg, dtype, Tq, S):
         o = _hip.op_attention(q, k, v, H, scale, family=fam).float()
         err = (o - ref).abs().max().item()
         assert err < tol, f"attention fam{fam} Tq={Tq} S={S}: max abs err {err}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_attention_running_reference_moves_late(built_lib, dtype):
+    """Scores that keep growing along the keys (and a burst in the last tile): the deferred running maximum of the flash kernels
+    has to be raised in the middle of the walk -- in the pipelined 32 x 32 x 16 kernel that is the rare path behind P.V(j) and
+    in front of the product of block j + 2.  Against torch fp32 on the same 16-bit inputs; the softmax is close to one-hot here,
+    so the error is that of the 16-bit scores: the bound is the generic kernel's error (eager rounding points) times two."""
+    from vall_e.vall_e import _hip
+    B, H, hd, T = 2, 8, 64, 384
+    d = H * hd
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q = torch.randn(B, T, d, generator=g)
+    k = torch.randn(B, T, d, generator=g) * torch.linspace(0.5, 4.0, T).view(1, T, 1)
+    k[:, -40:] *= 2.5
+    v = torch.randn(B, T, d, generator=g)
+    q, k, v = (t.to(dtype).to(DEV) for t in (q, k, v))
+    scale = math.sqrt(1.0 / hd)
+    ref = torch_attention(q, k, v, H, scale)
+    bound = 2.0 * (_hip.op_attention(q, k, v, H, scale, family=_hip.FAMILY_GENERIC).float() - ref).abs().max().item()
+    try:
+        for qg in (2, 32, 33):
+            _hip.set_attn_query_groups(qg)
+            o = _hip.op_attention(q, k, v, H, scale).float()
+            assert torch.isfinite(o).all()
+            err = (o - ref).abs().max().item()
+            assert err < bound, f"qg{qg} {dtype}: max abs err {err} (generic kernel x 2: {bound})"
+    finally:
+        _hip.set_attn_query_groups(0)
 
 
 def test_attention_self_packed_qkv_and_tiny_heads(built_lib):

@@ -971,7 +971,7 @@ int d3pm_ab_set(int knob, int value) {
     for (int m : big_modes)
       if (m == value) { k.big_mode = value; return D3PM_OK; }
   }
-  if (knob == D3PM_AB_ATTN_ARM && (value == 0 || value == 3 || (value >= 100 && value <= 164) || value == 228 || value == 201 || value == 202 || value == 300 || value == 301)) { k.attn_arm = value; return D3PM_OK; }
+  if (knob == D3PM_AB_ATTN_ARM && (value == 0 || value == 3 || (value >= 100 && value <= 164) || value == 228 || value == 201 || value == 202 || value == 300 || value == 301 || (value >= 320 && value <= 324))) { k.attn_arm = value; return D3PM_OK; }
   if (knob == D3PM_AB_GEMM_RING && (value == 0 || value == 1)) { k.ring = value; return D3PM_OK; }
   if (knob == D3PM_AB_GELU_TABLE && (value == 0 || value == 1)) { k.gelu_table = value; return D3PM_OK; }
   if (knob == D3PM_AB_LN_PROLOGUE && (value == 0 || value == 1)) { k.ln_prologue = value; return D3PM_OK; }
@@ -983,6 +983,11 @@ int d3pm_ab_set(int knob, int value) {
 int d3pm_debug_gemm_clock(unsigned long long* clocks_and_ticks) {
   D3PM_REQUIRE(clocks_and_ticks, D3PM_E_ARG, "d3pm_debug_gemm_clock: null pointer");
   return read_big_gemm_stamp(clocks_and_ticks);
+}
+
+int d3pm_debug_attn32_stamps(unsigned long long* out, int n) {
+  D3PM_REQUIRE(out && n > 0, D3PM_E_ARG, "d3pm_debug_attn32_stamps: bad arguments");
+  return read_attn32_stamps(out, n);
 }
 #endif
 

@@ -156,6 +156,11 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a);
 int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s);
 bool mfma_attention_supported(int dtype, const AttnArgs& a);
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s);
+bool mfma_attention32_supported(int dtype, const AttnArgs& a);   // d3pm_mfma_attn32.hip: self-attention on the 32 x 32 x 16 instruction
+int mfma_attention32(int dtype, const AttnArgs& a, hipStream_t s);
+#ifdef D3PM_ABLATIONS
+int read_attn32_stamps(unsigned long long* out, int n);
+#endif
 #ifdef D3PM_ABLATIONS
 bool panel64_ln_supported(int dtype, const LinearArgs& a, const LnPrologue& ln);
 bool ln_prologue_linear_applies(int dtype, const LinearArgs& a, const LnPrologue& ln);   // would mfma_linear pick the latency GEMM?

@@ -688,6 +688,15 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
 #else
   const int g_attn_qg = (tn.attn_query_groups == 1 || tn.attn_query_groups == 2) ? tn.attn_query_groups : 0;
 #endif
+  // The 32 x 32 x 16 kernel of d3pm_mfma_attn32.hip wherever it applies (whole 128-query blocks and 64-key tiles of a single
+  // problem: the self-attention of a DiT block) once its grid has two workgroups per CU (measured: 55.3 vs 65.3 us at 32
+  // utterances x 768 frames, 19.5 vs 20.3 at 32 x 384, 28.8 vs 30.8 at 16 x 768; tests/ab_attn32.py); below that the 64-query
+  // workgroups of the kernel below finish sooner.  attn_query_groups: 0 auto, 32 always, 33 always and the plain walk, 1 / 2 never.
+  {
+    const long long wgs32 = static_cast<long long>(a.Tq / 128) * a.H * a.B;
+    const int q = tn.attn_query_groups;
+    if ((q == 32 || q == 33 || (q == 0 && wgs32 >= 512)) && mfma_attention32_supported(dtype, a)) return mfma_attention32(dtype, a, s);
+  }
   const long long cross_wgs = static_cast<long long>((a.Tq + 255) / 256) * a.H * a.B;
   if ((g_attn_cross_resident >= 2 || (g_attn_cross_resident == 1 && cross_wgs >= 256)) && a.Q2 != nullptr && a.key_len == nullptr &&
       a.S <= BKV && a.S2 <= 4 * BKV) {

@@ -1,0 +1,610 @@
+// d3pm_mfma_attn32.hip -- self-attention of a DiT block on the 32 x 32 x 16 matrix instruction (head_dim 64, f16 / bf16), gfx950.
+//
+// Replaces the need_weights branch of torch's multi_head_attention_forward as called by DiTBlock.forward
+// (/root/reference/vall_e/vall_e/ar_discrete.py:132) at throughput batch sizes; d3pm_mfma_attn.hip keeps every other case
+// (cross-attention, ragged keys, key lengths, one or two utterances).
+//
+// Why a second kernel.  At head_dim 64 a score costs 256 flop of matrix work and one v_exp_f32, and an MFMA holds its SIMD's
+// vector issue port for 8 cycles whatever its shape: 8 of the 16 cycles of v_mfma_f32_16x16x32, 8 of the 32 of
+// v_mfma_f32_32x32x16 (MI355X_MICROARCH.md, constants table).  With the 16 x 16 instruction the softmax of one wave therefore
+// cannot run under the matrix products of its SIMD partner -- measured in round 2: products alone 34.5 us, softmax alone 28.9,
+// together 56.5 -- with the 32 x 32 instruction three quarters of the issue slots stay open.  Same flash-style numerics as
+// attn_mfma_hd64 (scores in the log2 domain relative to a deferred running reference, un-normalised 16-bit probabilities into
+// the second product, fp32 row sums divided out at the end) except that the row sum adds the fp32 probabilities on the VALU
+// (a ones-row on this instruction would cost half a P.V product).
+//
+// Workgroup = 4 wave64 = 128 queries of one (utterance, head), two workgroups per CU; a wave owns 32 queries and walks the
+// keys in tiles of 64:
+//   * S^T = K . Q^T: A = K fragment from LDS (lane: key l & 31, 8 head-dim elements 16 ks + 8 (l >> 5)), B = Q fragment held
+//     in registers; a lane ends up with 2 x 16 scores of ONE query (keys 32 kb + 8 j + 4 (l >> 5) + r), so the row maximum is
+//     in-lane plus one v_permlane32_swap;
+//   * the exponentiated scores, eight consecutive registers at a time, ARE the B operand of O^T += V^T . P (contraction slot
+//     8 (l >> 5) + i <-> key 16 t + 8 (i >> 2) + 4 (l >> 5) + (i & 3), the same permutation on both operands);
+//   * V stays row-major in LDS and is read column-major with ds_read_b64_tr_b16 (4 keys x 16 columns per 16-lane group);
+//   * K / V tiles are staged global -> registers -> LDS one tile ahead, one barrier per tile; 128-byte LDS rows with the
+//     16-byte chunks XOR-swizzled (K: (row >> 1) & 7 -- the b128 fragment reads of 32 rows x one chunk; V: ((row >> 1) & 1)
+//     << 2 -- the transposed reads of 4 rows x 64 bytes), both conflict-free by construction.
+#include "d3pm_kernels.h"
+
+namespace d3pm {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+constexpr int HD = 64, BKV = 64, ROWB = 128;
+constexpr int TILE = BKV * ROWB;   // 8 KiB per K or V tile
+constexpr float kDefer = 8.0f;     // log2 of the largest un-normalised probability tolerated before m_ref is raised
+
+template <typename T> __device__ __forceinline__ floatx16 mma32(uint4 a, uint4 b, floatx16 c);
+template <> __device__ __forceinline__ floatx16 mma32<f16>(uint4 a, uint4 b, floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ floatx16 mma32<bf16>(uint4 a, uint4 b, floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int k_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int v_off(int row, int chunk) { return row * ROWB + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
+
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  typedef T pair __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2v){a, b}, pair));
+}
+
+// the value of lane l ^ 32 (v_permlane32_swap of two copies leaves one holding the low half twice, the other the high half twice)
+__device__ __forceinline__ void halves(float x, float& lo, float& hi) {
+  lo = x;
+  hi = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+}
+
+// STAMP (A/B library only): wave 0 of the first workgroup and of one in the middle of the grid records the shader clock at eight
+// points of every key tile (d3pm_debug_attn32_stamps); see the stamp() calls for the points
+constexpr int kStampTiles = 12, kStampPoints = 8;
+__device__ unsigned long long g_attn32_stamp[2 * kStampTiles * kStampPoints];
+
+template <typename T, int STAMP = 0>   // 1: coarse (start / end of every 32nd workgroup: shader clocks + 100 MHz ticks), 2: per tile
+__global__ __launch_bounds__(256, 2) void attn32_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
+                                                      const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo, int Tq,
+                                                      int S, float scale, int H, int n_qblocks) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE];   // [buffer][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long stamp_c = 0, stamp_r = 0;
+  if constexpr (STAMP == 1) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
+  // XCD-aware order: each XCD gets a contiguous range of (utterance, head, query-block) ids, so the query blocks that share
+  // one K / V share one L2
+  int bid;
+  {
+    const int nblocks = gridDim.x, q = nblocks >> 3, r = nblocks & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int qb = bid % n_qblocks, h = (bid / n_qblocks) % H, b = bid / (n_qblocks * H);
+  const int q0 = (qb * 4 + wave) * 32;
+  const int qn = lane & 31, hh = lane >> 5;
+  const T* Kb = Kp + static_cast<size_t>(b) * S * ldkv + h * HD;
+  const T* Vb = Vp + static_cast<size_t>(b) * S * ldkv + h * HD;
+
+  // Q fragments (B operand of S^T = K . Q^T): lane holds q[query][16 ks + 8 hh .. +7], pre-scaled by sqrt(1/hd) * log2(e)
+  const float qscale = scale * 1.4426950408889634f;
+  uint4 qf[4];
+  {
+    const T* qp = Q + (static_cast<size_t>(b) * Tq + q0 + qn) * ldq + h * HD + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      typedef T tvec8 __attribute__((ext_vector_type(8)));
+      const tvec8 e = __builtin_bit_cast(tvec8, *reinterpret_cast<const uint4*>(qp + ks * 16));
+      qf[ks] = uint4{pack2<T>(static_cast<float>(e[0]) * qscale, static_cast<float>(e[1]) * qscale),
+                     pack2<T>(static_cast<float>(e[2]) * qscale, static_cast<float>(e[3]) * qscale),
+                     pack2<T>(static_cast<float>(e[4]) * qscale, static_cast<float>(e[5]) * qscale),
+                     pack2<T>(static_cast<float>(e[6]) * qscale, static_cast<float>(e[7]) * qscale)};
+    }
+  }
+
+  // staging: thread -> 2 x 16 B of the K tile and 2 x 16 B of the V tile (rows r0s and r0s + 32, chunk chs)
+  const int r0s = tid >> 3, chs = tid & 7;
+  const int ko0 = k_off(r0s, chs), ko1 = k_off(r0s + 32, chs), vo0 = v_off(r0s, chs), vo1 = v_off(r0s + 32, chs);
+  struct Staged { uint4 k0, k1, v0, v1; };
+  const uint32_t lo0 = static_cast<uint32_t>(r0s * ldkv + chs * 8) * 2u, lo1 = lo0 + static_cast<uint32_t>(32 * ldkv) * 2u;
+  auto load_tile = [=](int tile) -> Staged {
+    Staged st;
+    const char* kt = reinterpret_cast<const char*>(Kb + static_cast<size_t>(tile) * BKV * ldkv);
+    const char* vt = reinterpret_cast<const char*>(Vb + static_cast<size_t>(tile) * BKV * ldkv);
+    st.k0 = *reinterpret_cast<const uint4*>(kt + lo0);
+    st.k1 = *reinterpret_cast<const uint4*>(kt + lo1);
+    st.v0 = *reinterpret_cast<const uint4*>(vt + lo0);
+    st.v1 = *reinterpret_cast<const uint4*>(vt + lo1);
+    return st;
+  };
+  auto store_tile = [=](char* base, const Staged& st) {
+    *reinterpret_cast<uint4*>(base + ko0) = st.k0;
+    *reinterpret_cast<uint4*>(base + ko1) = st.k1;
+    *reinterpret_cast<uint4*>(base + TILE + vo0) = st.v0;
+    *reinterpret_cast<uint4*>(base + TILE + vo1) = st.v1;
+  };
+
+  const int n_tiles = S / BKV;
+  Staged st = load_tile(0);
+  store_tile(smem, st);
+  __syncthreads();
+
+  float m_ref = 0.f, lsum = 0.f;
+  floatx16 negm, acc_o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { negm[i] = 0.f; acc_o[0][i] = 0.f; acc_o[1][i] = 0.f; }
+
+  // per-lane LDS offsets of the fragment reads, computed once (the XOR swizzles only touch address bits that the tile-local
+  // constants do not):
+  //   K (b128): row 32 kb + qn, chunk 2 ks + hh                                   -> ok[ks] + kb * 4096
+  //   V (tr b64): row 16 t + 8 sub + 4 hh + (qi >> 2), columns 32 db + 16 cb + 4 (qi & 3) -> ov[db] + (16 t + 8 sub) * 128
+  int ok[4], ov[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) ok[ks] = k_off(qn, 2 * ks + hh);
+  {
+    const int qi = lane & 15, cb = (lane >> 4) & 1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int col = 32 * db + 16 * cb + 4 * (qi & 3);
+      ov[db] = v_off(4 * hh + (qi >> 2), col >> 3) + (col & 7) * 2;
+    }
+  }
+
+  const int stamp_slot = blockIdx.x == 0 ? 0 : (blockIdx.x == (gridDim.x / 16) * 8 + 3 ? 1 : -1);
+  auto stamp = [&](int tile, int point) __attribute__((always_inline)) {
+    if constexpr (STAMP == 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (stamp_slot >= 0 && tid == 0 && tile < kStampTiles)
+        g_attn32_stamp[(stamp_slot * kStampTiles + tile) * kStampPoints + point] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto do_tile = [&](int tile, auto BUF_) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(BUF_)::value;
+    stamp(tile, 0);                                     // top of the tile (behind the previous tile's barrier)
+    const char* kb_ = smem + BUF * 2 * TILE;
+    const char* vb_ = kb_ + TILE;
+    const bool more = tile + 1 < n_tiles;
+    if (more) st = load_tile(tile + 1);
+    stamp(tile, 1);                                     // the next tile's global loads are issued
+
+    // ---- S^T tile: 64 keys x 32 queries; the accumulator starts at -m_ref, so the scores leave the matrix pipe relative to
+    // the running reference
+    floatx16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(kb_ + ok[ks] + kb * 32 * ROWB);
+        s[kb] = mma32<T>(kf, qf[ks], ks == 0 ? negm : s[kb]);
+      }
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s[0][i]), s[1][i]);
+    // Deferred maximum: m_ref only moves when some score of the wave exceeds it by more than 2^kDefer (or on the first tile)
+    if (tile == 0 || __any(mx > kDefer)) {               // wave-uniform
+      float a, c;
+      halves(mx, a, c);                                  // lanes l and l ^ 32 share a query
+      mx = fmaxf(a, c);
+      const float delta = tile == 0 ? mx : fmaxf(mx, 0.f);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[0][i] -= delta; s[1][i] -= delta; }
+      if (tile != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        lsum *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc_o[0][i] *= alpha; acc_o[1][i] *= alpha; }
+      }
+      m_ref += delta;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[i] = -m_ref;
+    }
+    stamp(tile, 2);                                     // scores available: K reads, 8 MFMAs, the maximum (+ a rare rescale)
+    uint4 pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i]);
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) { t0 += s[kb][i]; t1 += s[kb][i + 1]; }
+      lsum += t0 + t1;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        pf[2 * kb + u] = uint4{pack2<T>(s[kb][8 * u + 0], s[kb][8 * u + 1]), pack2<T>(s[kb][8 * u + 2], s[kb][8 * u + 3]),
+                               pack2<T>(s[kb][8 * u + 4], s[kb][8 * u + 5]), pack2<T>(s[kb][8 * u + 6], s[kb][8 * u + 7])};
+    }
+
+    stamp(tile, 3);                                     // exponentials, row sum, packing
+    // ---- O^T += V^T . P ----
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        typedef short4v __attribute__((address_space(3))) * lds_ptr;
+        const short4v va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb_ + ov[db] + (16 * t) * ROWB));
+        const short4v vc = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vb_ + ov[db] + (16 * t + 8) * ROWB));
+        const uint2 lo = __builtin_bit_cast(uint2, va), hi = __builtin_bit_cast(uint2, vc);
+        acc_o[db] = mma32<T>(uint4{lo.x, lo.y, hi.x, hi.y}, pf[t], acc_o[db]);
+      }
+    stamp(tile, 4);                                     // V reads and the 8 P.V MFMAs issued
+    if constexpr (STAMP == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(tile, 5);                                     // the next tile's global loads have returned
+    if (more) store_tile(smem + (BUF ^ 1) * 2 * TILE, st);
+    stamp(tile, 6);                                     // its LDS stores issued
+    __syncthreads();
+    stamp(tile, 7);                                     // barrier passed
+  };
+  for (int tile = 0; tile < n_tiles; tile += 2) {
+    do_tile(tile, std::integral_constant<int, 0>{});
+    if (tile + 1 < n_tiles) do_tile(tile + 1, std::integral_constant<int, 1>{});
+  }
+
+  float la, lc;
+  halves(lsum, la, lc);
+  const float inv = 1.0f / (la + lc);
+  T* op = O + (static_cast<size_t>(b) * Tq + q0 + qn) * ldo + h * HD + 4 * hh;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint2 o{pack2<T>(acc_o[db][4 * j] * inv, acc_o[db][4 * j + 1] * inv), pack2<T>(acc_o[db][4 * j + 2] * inv, acc_o[db][4 * j + 3] * inv)};
+      *reinterpret_cast<uint2*>(op + 32 * db + 8 * j) = o;
+    }
+  if constexpr (STAMP == 1) {
+    if (tid == 0 && (blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 48) {
+      unsigned long long* o = g_attn32_stamp + (blockIdx.x >> 5) * 4;
+      o[0] = stamp_c; o[1] = __builtin_amdgcn_s_memtime(); o[2] = stamp_r; o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+}
+
+// ---- the software-pipelined form ---------------------------------------------------------------------------------------
+// One wave's instruction stream carries matrix and vector work of DIFFERENT 32-key blocks side by side: two waves on a SIMD do
+// not overlap one's MFMAs with the other's exponentials (they add up: round 2), but inside one stream the 24 free cycles of
+// every 32 x 32 x 16 MFMA take vector instructions for nothing.  Per 32-key block j (two per key tile):
+//   phase 1: S(j + 1) = K(j + 1) . Q^T [4 MFMAs]  beside  exp2 of S(j), its packing into P(j), the V(j) fragment reads
+//   phase 2: O^T += V(j)^T . P(j)     [4 MFMAs]  beside  the rest of exp2 / packing, the row sum of P(j), the K(j + 2)
+//            fragment reads and the maximum of S(j + 1)
+// and then the deferred-maximum test on S(j + 1) (rarely taken: rescale O, l and S(j + 1), raise m_ref) -- behind P.V(j) and
+// the sum of P(j), in front of the product of block j + 2, so every number is the one the plain walk computes.
+// The groups are pinned with sched_barrier(0) (hipcc otherwise hoists the exponentials in front of the products).  K(j + 1)
+// of the next tile is read half a tile before that tile's turn: three LDS buffers, tiles staged two ahead, still one barrier
+// per tile.
+// ABL != 0: timing-only ablations for tools/probe_attn32.hip (WRONG results): 1 no exponentials, 2 no S products, 4 no P.V
+// products, 8 no V fragment reads, 16 no K fragment reads, 32 no staging / barrier after the prologue, 64 no maximum / test,
+// 128 no packing, 256 no row sum
+template <typename T, int STAMP = 0, int ABL = 0>
+__global__ __launch_bounds__(256, 3) void attn32p_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
+                                                       const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo, int Tq,
+                                                       int S, float scale, int H, int n_qblocks) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * 2 * TILE];   // [buffer][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long stamp_c = 0, stamp_r = 0;
+  if constexpr (STAMP == 1) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
+  int bid;
+  {
+    const int nblocks = gridDim.x, q = nblocks >> 3, r = nblocks & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int qb = bid % n_qblocks, h = (bid / n_qblocks) % H, b = bid / (n_qblocks * H);
+  const int q0 = (qb * 4 + wave) * 32;
+  const int qn = lane & 31, hh = lane >> 5;
+  const T* Kb = Kp + static_cast<size_t>(b) * S * ldkv + h * HD;
+  const T* Vb = Vp + static_cast<size_t>(b) * S * ldkv + h * HD;
+
+  const float qscale = scale * 1.4426950408889634f;
+  uint4 qf[4];
+  {
+    const T* qp = Q + (static_cast<size_t>(b) * Tq + q0 + qn) * ldq + h * HD + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      typedef T tvec8 __attribute__((ext_vector_type(8)));
+      const tvec8 e = __builtin_bit_cast(tvec8, *reinterpret_cast<const uint4*>(qp + ks * 16));
+      qf[ks] = uint4{pack2<T>(static_cast<float>(e[0]) * qscale, static_cast<float>(e[1]) * qscale),
+                     pack2<T>(static_cast<float>(e[2]) * qscale, static_cast<float>(e[3]) * qscale),
+                     pack2<T>(static_cast<float>(e[4]) * qscale, static_cast<float>(e[5]) * qscale),
+                     pack2<T>(static_cast<float>(e[6]) * qscale, static_cast<float>(e[7]) * qscale)};
+    }
+  }
+
+  const int r0s = tid >> 3, chs = tid & 7;
+  const int ko0 = k_off(r0s, chs), ko1 = k_off(r0s + 32, chs), vo0 = v_off(r0s, chs), vo1 = v_off(r0s + 32, chs);
+  struct Staged { uint4 k0, k1, v0, v1; };
+  const uint32_t lo0 = static_cast<uint32_t>(r0s * ldkv + chs * 8) * 2u, lo1 = lo0 + static_cast<uint32_t>(32 * ldkv) * 2u;
+  auto load_tile = [=](int tile) -> Staged {
+    Staged st;
+    const char* kt = reinterpret_cast<const char*>(Kb + static_cast<size_t>(tile) * BKV * ldkv);
+    const char* vt = reinterpret_cast<const char*>(Vb + static_cast<size_t>(tile) * BKV * ldkv);
+    st.k0 = *reinterpret_cast<const uint4*>(kt + lo0);
+    st.k1 = *reinterpret_cast<const uint4*>(kt + lo1);
+    st.v0 = *reinterpret_cast<const uint4*>(vt + lo0);
+    st.v1 = *reinterpret_cast<const uint4*>(vt + lo1);
+    return st;
+  };
+  auto store_tile = [=](char* base, const Staged& st) {
+    *reinterpret_cast<uint4*>(base + ko0) = st.k0;
+    *reinterpret_cast<uint4*>(base + ko1) = st.k1;
+    *reinterpret_cast<uint4*>(base + TILE + vo0) = st.v0;
+    *reinterpret_cast<uint4*>(base + TILE + vo1) = st.v1;
+  };
+
+  const int n_tiles = S / BKV;
+  Staged st = load_tile(0);
+  store_tile(smem, st);
+  if (n_tiles > 1) {
+    st = load_tile(1);
+    store_tile(smem + 2 * TILE, st);
+  }
+  __syncthreads();
+
+  int ok[4], ov[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) ok[ks] = k_off(qn, 2 * ks + hh);
+  {
+    const int qi = lane & 15, cb = (lane >> 4) & 1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int col = 32 * db + 16 * cb + 4 * (qi & 3);
+      ov[db] = v_off(4 * hh + (qi >> 2), col >> 3) + (col & 7) * 2;
+    }
+  }
+
+  float m_ref = 0.f;
+  float ls[4] = {0.f, 0.f, 0.f, 0.f};
+  floatx16 negm, acc_o[2], sA, sB;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { negm[i] = 0.f; acc_o[0][i] = 0.f; acc_o[1][i] = 0.f; }
+  uint4 kf[4];
+  auto read_k = [&](const char* kblock) __attribute__((always_inline)) {   // the four K fragments of a 32-key block
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(kblock + ok[ks]);
+  };
+  auto row_max = [&](const floatx16& s) __attribute__((always_inline)) -> float {
+    float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+    for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s[i]), s[i + 1]);
+    return mx;
+  };
+
+  // ---- prologue: the scores of block 0 and the first reference
+  read_k(smem);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) sA = mma32<T>(kf[ks], qf[ks], ks == 0 ? negm : sA);
+  read_k(smem + 32 * ROWB);
+  {
+    float a, c;
+    halves(row_max(sA), a, c);
+    const float delta = fmaxf(a, c);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sA[i] -= delta;
+    m_ref = delta;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = -m_ref;
+  }
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define EXP2(x) ((ABL & 1) ? (x) + 1.0f : __builtin_amdgcn_exp2f(x))
+  // one block: sc = S(j) relative to m_ref; NEXT: sn <- S(j + 1), kf holds K(j + 1) on entry and K(j + 2) (from knext) on exit;
+  // vblock = the 32 V rows of block j
+  // STG: which half of the tile staged two ahead this block carries through registers (0 none, 1 the K rows, 2 the V rows): a
+  // half lives in 8 registers for one block instead of the whole tile in 16 for two (three waves per SIMD: 168 registers)
+  auto block = [&](floatx16& sc, floatx16& sn, const char* vblock, const char* knext, auto NEXT_, auto STG_, int stile, char* sdst)
+      __attribute__((always_inline)) {
+    constexpr bool NEXT = decltype(NEXT_)::value;
+    constexpr int STG = (ABL & 32) ? 0 : decltype(STG_)::value;
+    typedef short4v __attribute__((address_space(3))) * lds_ptr;
+    uint4 vf[2], pf, h0, h1;
+    auto read_v = [&](int t, int db) __attribute__((always_inline)) {
+      if constexpr (ABL & 8) {
+        vf[db] = uint4{0x3c003c00u + t, 0x3c003800u + db, 0x38003c00u, 0x3c003c00u ^ static_cast<uint32_t>(lane)};
+      } else {
+        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vblock + ov[db] + (16 * t) * ROWB)));
+        const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vblock + ov[db] + (16 * t + 8) * ROWB)));
+        vf[db] = uint4{lo.x, lo.y, hi.x, hi.y};
+      }
+    };
+    // Vector work per MFMA gap is sized from tools/probe_issue2.hip: beside one v_mfma_f32_32x32x16 (32 cycles) fit three v_exp_f32
+    // or v_cvt_pk (8 - 10 cycles each) or six plain adds; v_pk_add_f32 / v_pk_mul_f32 do NOT overlap with the matrix pipe (three
+    // per gap: 62 cycles per gap), so the row sum is four chains of plain v_add_f32 from asm (hipcc would pair them)
+    auto e4 = [&](int i) __attribute__((always_inline)) {
+      sc[i] = EXP2(sc[i]); sc[i + 1] = EXP2(sc[i + 1]); sc[i + 2] = EXP2(sc[i + 2]); sc[i + 3] = EXP2(sc[i + 3]);
+      if constexpr (!(ABL & 256)) {
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls[0]) : "v"(sc[i]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls[1]) : "v"(sc[i + 1]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls[2]) : "v"(sc[i + 2]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls[3]) : "v"(sc[i + 3]));
+      }
+    };
+    auto pack8 = [&](int i) __attribute__((always_inline)) {
+      if constexpr (ABL & 128) pf = uint4{__builtin_bit_cast(uint32_t, sc[i]), __builtin_bit_cast(uint32_t, sc[i + 2]), __builtin_bit_cast(uint32_t, sc[i + 4]), __builtin_bit_cast(uint32_t, sc[i + 6])};
+      else pf = uint4{pack2<T>(sc[i], sc[i + 1]), pack2<T>(sc[i + 2], sc[i + 3]), pack2<T>(sc[i + 4], sc[i + 5]), pack2<T>(sc[i + 6], sc[i + 7])};
+    };
+    auto pv = [&](int db, int slot) __attribute__((always_inline)) {
+      if constexpr (ABL & 4) acc_o[db][slot] += __builtin_bit_cast(float, pf.x) + __builtin_bit_cast(float, vf[db].y);
+      else acc_o[db] = mma32<T>(vf[db], pf, acc_o[db]);
+    };
+    SB();
+    if constexpr (STG != 0) {      // unconditional (a branch here splits the block and hipcc sinks the vector work behind it): past the
+      // end the last tile is staged again, into a buffer that is no longer read
+      const char* gt = reinterpret_cast<const char*>((STG == 1 ? Kb : Vb) + static_cast<size_t>(stile < n_tiles ? stile : n_tiles - 1) * BKV * ldkv);
+      h0 = *reinterpret_cast<const uint4*>(gt + lo0);
+      h1 = *reinterpret_cast<const uint4*>(gt + lo1);
+    }
+    read_v(0, 0);
+    read_v(0, 1);
+    SB();
+    // ---- phase 1
+    if constexpr (NEXT) { if constexpr (ABL & 2) sn = negm; else sn = mma32<T>(kf[0], qf[0], negm); }
+    e4(0);
+    SB();
+    if constexpr (NEXT && !(ABL & 2)) sn = mma32<T>(kf[1], qf[1], sn);
+    e4(4);
+    SB();
+    if constexpr (NEXT && !(ABL & 2)) sn = mma32<T>(kf[2], qf[2], sn);
+    pack8(0);
+    SB();
+    if constexpr (NEXT && !(ABL & 2)) sn = mma32<T>(kf[3], qf[3], sn);
+    e4(8);
+    SB();
+    // ---- phase 2
+    pv(0, 0);
+    read_v(1, 0);                                          // the fragment register is free once the product is issued
+    e4(12);
+    SB();
+    pv(1, 0);
+    read_v(1, 1);
+    if constexpr (NEXT && !(ABL & 16)) read_k(knext);
+    pack8(8);
+    SB();
+    pv(0, 1);
+    float mx = 0.f;
+    if constexpr (NEXT && !(ABL & 64)) mx = row_max(sn);
+    SB();
+    pv(1, 1);
+    if constexpr (STG != 0) {
+      *reinterpret_cast<uint4*>(sdst + (STG == 1 ? ko0 : TILE + vo0)) = h0;
+      *reinterpret_cast<uint4*>(sdst + (STG == 1 ? ko1 : TILE + vo1)) = h1;
+    }
+    SB();
+    if constexpr (NEXT && !(ABL & 64)) {
+      if (__builtin_expect(__any(mx > kDefer), 0)) {       // wave-uniform, rare
+        float a, c;
+        halves(mx, a, c);                                  // lanes l and l ^ 32 share a query
+        const float delta = fmaxf(fmaxf(a, c), 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        m_ref += delta;
+        const float nm = -m_ref;
+        // in place, from asm: as plain C++ the updates become loop-carried phis that hipcc resolves with sixteen v_mov_b64 per
+        // block on the COMMON path
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          asm volatile("v_sub_f32 %0, %0, %1" : "+v"(sn[i]) : "v"(delta));
+          asm volatile("v_mul_f32 %0, %0, %1" : "+v"(acc_o[0][i]) : "v"(alpha));
+          asm volatile("v_mul_f32 %0, %0, %1" : "+v"(acc_o[1][i]) : "v"(alpha));
+          asm volatile("v_mov_b32 %0, %1" : "+v"(negm[i]) : "v"(nm));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(ls[i]) : "v"(alpha));
+      }
+    }
+    SB();
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  using StK = std::integral_constant<int, 1>;
+  using StV = std::integral_constant<int, 2>;
+  using St0 = std::integral_constant<int, 0>;
+
+  int cur = 0, nx1 = 2 * TILE, nx2 = 4 * TILE;               // byte offsets of the buffers of tiles i, i + 1, i + 2
+  // every tile but the last: both blocks have a successor (one straight-line body: with the last tile's shorter second block
+  // inside the loop hipcc moves the output accumulators between two register sets in every block)
+  for (int i = 0; i + 1 < n_tiles; ++i) {
+    const char* vb = smem + cur + TILE;
+    block(sA, sB, vb, smem + nx1, Yes{}, StK{}, i + 2, smem + nx2);                     // keys 0..31 of tile i; then K(tile i + 1, first half)
+    block(sB, sA, vb + 32 * ROWB, smem + nx1 + 32 * ROWB, Yes{}, StV{}, i + 2, smem + nx2);
+    if constexpr (!(ABL & 32)) __syncthreads();
+    const int t = cur;
+    cur = nx1; nx1 = nx2; nx2 = t;
+  }
+  {
+    const char* vb = smem + cur + TILE;
+    block(sA, sB, vb, smem, Yes{}, St0{}, 0, smem);           // (the K fragments read here are not used)
+    block(sB, sA, vb + 32 * ROWB, smem, No{}, St0{}, 0, smem);
+  }
+#undef SB
+#undef EXP2
+
+  float la, lc;
+  halves((ls[0] + ls[1]) + (ls[2] + ls[3]), la, lc);
+  const float inv = 1.0f / (la + lc);
+  T* op = O + (static_cast<size_t>(b) * Tq + q0 + qn) * ldo + h * HD + 4 * hh;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint2 o{pack2<T>(acc_o[db][4 * j] * inv, acc_o[db][4 * j + 1] * inv), pack2<T>(acc_o[db][4 * j + 2] * inv, acc_o[db][4 * j + 3] * inv)};
+      *reinterpret_cast<uint2*>(op + 32 * db + 8 * j) = o;
+    }
+  if constexpr (STAMP == 1) {
+    if (tid == 0 && (blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 48) {
+      unsigned long long* o = g_attn32_stamp + (blockIdx.x >> 5) * 4;
+      o[0] = stamp_c; o[1] = __builtin_amdgcn_s_memtime(); o[2] = stamp_r; o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+// whole 128-query blocks and whole 64-key tiles of a single problem without key lengths: the self-attention of a DiT block
+bool mfma_attention32_supported(int dtype, const AttnArgs& a) {
+  if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
+  if (a.hd != HD || a.Q2 != nullptr || a.key_len != nullptr) return false;
+  if (a.Tq < 128 || a.Tq % 128 || a.S < BKV || a.S % BKV) return false;
+  if (a.ldq % 8 || a.ldkv % 8 || a.ldo % 4) return false;
+  return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 8);
+}
+
+#ifdef D3PM_ABLATIONS
+int read_attn32_stamps(unsigned long long* out, int n) {
+  const int total = 2 * kStampTiles * kStampPoints;
+  D3PM_CHECK_HIP(hipDeviceSynchronize());
+  D3PM_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn32_stamp), sizeof(unsigned long long) * (n < total ? n : total)));
+  return D3PM_OK;
+}
+#endif
+
+int mfma_attention32(int dtype, const AttnArgs& a, hipStream_t s) {
+  const int n_qblocks = a.Tq / 128;
+  const dim3 grid(static_cast<unsigned>(n_qblocks * a.H * a.B)), block(256);
+#ifdef D3PM_ABLATIONS
+  if (ab_knobs().attn_arm >= 321 && ab_knobs().attn_arm <= 324 && dtype == D3PM_BF16) {      // coarse stamps: 321 the plain walk, 322 the pipelined one; 323 / 324: the same at ONE workgroup per CU (idle dynamic LDS)
+    const int arm = ab_knobs().attn_arm;
+    const size_t pad = arm >= 323 ? 72 * 1024 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_hd64<bf16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32p_hd64<bf16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr_set = true;
+    }
+    if (arm == 321 || arm == 323)
+      attn32_hd64<bf16, 1><<<grid, block, pad, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), static_cast<const bf16*>(a.V),
+                                                  a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks);
+    else
+      attn32p_hd64<bf16, 1><<<grid, block, pad, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), static_cast<const bf16*>(a.V),
+                                                   a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks);
+    D3PM_LAUNCH_CHECK();
+    return D3PM_OK;
+  }
+  if (ab_knobs().attn_arm == 320 && dtype == D3PM_BF16) {      // the stamped build (timing probe)
+    attn32_hd64<bf16, 2><<<grid, block, 0, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), static_cast<const bf16*>(a.V),
+                                                   a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks);
+    D3PM_LAUNCH_CHECK();
+    return D3PM_OK;
+  }
+#endif
+  if (tune_of(a.tune).attn_query_groups != 33) {           // 33: the plain walk (A/B against the pipelined one)
+    if (dtype == D3PM_F16)
+      attn32p_hd64<f16><<<grid, block, 0, s>>>(static_cast<const f16*>(a.Q), a.ldq, static_cast<const f16*>(a.K), static_cast<const f16*>(a.V),
+                                               a.ldkv, static_cast<f16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks);
+    else
+      attn32p_hd64<bf16><<<grid, block, 0, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), static_cast<const bf16*>(a.V),
+                                                a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks);
+    D3PM_LAUNCH_CHECK();
+    return D3PM_OK;
+  }
+  if (dtype == D3PM_F16)
+    attn32_hd64<f16><<<grid, block, 0, s>>>(static_cast<const f16*>(a.Q), a.ldq, static_cast<const f16*>(a.K), static_cast<const f16*>(a.V),
+                                            a.ldkv, static_cast<f16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks);
+  else
+    attn32_hd64<bf16><<<grid, block, 0, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), static_cast<const bf16*>(a.V),
+                                             a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks);
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+}  // namespace d3pm

@@ -182,6 +182,7 @@ AB_SIGNATURES = {
     "d3pm_op_final_sample": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.POINTER(ScheduleC), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]),
     "d3pm_debug_gemm_clock": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "d3pm_debug_attn32_stamps": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
 }
 AB_GEMM_BIG_MODE, AB_ATTN_ARM, AB_GEMM_RING, AB_GELU_TABLE, AB_LN_PROLOGUE, AB_FUSED_FINAL_SAMPLE = range(6)
 _is_ab = False
@@ -801,7 +802,7 @@ def set_gemm_variant(v: int):
 
 
 def set_attn_query_groups(v: int):
-    if v not in (0, 1, 2):
+    if v not in (0, 1, 2, 32, 33):
         raise D3PMError(f"attn_query_groups {v}: not a shipped schedule (include/d3pm_hip.h)")
     lib()
     TUNING.attn_query_groups = v
@@ -890,6 +891,15 @@ def gemm_clock_ghz() -> float:
     buf = (C.c_uint64 * 2)()
     check(lib().d3pm_debug_gemm_clock(buf), "d3pm_debug_gemm_clock")
     return buf[0] / max(buf[1], 1) * 0.1
+
+
+def attn32_stamps():
+    """[2][12][8] shader-clock stamps of the last attn32 launch under set_attn_arm(320) (include/d3pm_hip_ab.h); synchronises."""
+    if not _is_ab:
+        raise D3PMError("d3pm_debug_attn32_stamps lives in libd3pm_hip_ab.so (use_ab_library())")
+    buf = (C.c_uint64 * 192)()
+    check(lib().d3pm_debug_attn32_stamps(buf, 192), "d3pm_debug_attn32_stamps")
+    return [[[int(buf[(s * 12 + t) * 8 + p]) for p in range(8)] for t in range(12)] for s in range(2)]
 
 
 # ---- timing hooks: a d3pm_prof handle attached to the default Tuning ------------------------------------------------------
