@@ -81,7 +81,7 @@ def main():
         q = torch.randn(32, Tq, 512, device=DEV).to(dtype)
         kv = torch.randn(32, S, 1024, device=DEV).to(dtype)
         line = f"{name:8s} Tq={Tq} S={S:4d}:"
-        for qg in ((0,) if quick else (1, 2)):
+        for qg in ((0,) if quick else (1, 2, 32)):
             _hip.set_attn_query_groups(qg)
             t = timeit(lambda: _hip.op_attention(q, kv[..., :512], kv[..., 512:], 8, 0.125, family=_hip.FAMILY_MFMA))
             line += f" | qg{qg}: {t * 1e6:7.1f} us {4 * 32 * 8 * Tq * S * 64 / t / 1e12:7.1f} TF/s"
