@@ -82,9 +82,12 @@ enum {
  *   attn_query_groups  schedule of the MFMA self-attention: 0 = auto -- the software-pipelined 32 x 32 x 16 kernel (one 32-query
  *                      group per wave, three workgroups per CU) for whole 128-query blocks and 64-key tiles once that grid has two
  *                      workgroups per CU, else the 16 x 16 x 32 kernel with 2 sixteen-query groups per wave when that still gives
- *                      >= 4 workgroups per CU, else 1; 1 or 2 = the 16 x 16 x 32 kernel with that many groups; 32 = the 32 x 32 x 16
- *                      kernel wherever it applies; 33 = as 32 without the software pipeline.  (The two instruction shapes
- *                      accumulate in different orders: results agree to rounding noise, not bit for bit.)
+ *                      >= 4 workgroups per CU, else 1 -- and at one or two utterances (batch * canvas <= 1536 rows, the regime of
+ *                      the latency GEMM) the key-split kernel: four waves share 32 queries and each walks every fourth 64-key tile, the partial
+ *                      softmax states combined at the end; 1 or 2 = the 16 x 16 x 32 kernel with that many groups; 4 = the
+ *                      key-split kernel wherever it applies; 32 = the 32 x 32 x 16 kernel wherever it applies; 33 = as 32 without
+ *                      the software pipeline.  (The schedules accumulate in different orders: results agree to rounding noise,
+ *                      not bit for bit; within one schedule a result does not depend on the batch it rides in.)
  *   attn_pair_sequential  a paired attention launch (text + prompt cross-attention) on the tile-by-tile kernel: 2 = every
  *                      workgroup runs both problems one after the other; 0 = the second half of the grid takes problem 2;
  *                      1 (default) = auto: sequential while that still leaves >= 2 workgroups per CU.
@@ -95,7 +98,10 @@ enum {
  *   row_panel          bit mask of the block's projections that run as row-panel launches (d3pm_op_linear_rowpanel) when
  *                      d_model = 512, the dtype is 16-bit and batch * canvas is a multiple of 96: 1 = self-attention
  *                      out-projection + norm2 | norm22, 2 = both cross-attention out-projections + norm3 / FiLM, 4 = fc2 + the
- *                      next block's norm1.  Default 3 (fc2 measured slower fused).
+ *                      next block's norm1; 8 = at one or two utterances (batch * canvas <= 2048 rows, where no row panel applies)
+ *                      both cross-attention out-projections as ONE launch of the latency GEMM: two products through one resident
+ *                      weight panel, the first result kept in registers (same bits as the two launches it replaces).
+ *                      Default 11 (fc2 measured slower fused).
  *   workspace_alias    1 (default) = the packed qkv rows, the MLP hidden rows and the logits of an iteration share one
  *                      workspace region (never live together); 0 = separate regions.  d3pm_workspace_bytes and the step /
  *                      loop calls must see the same value.

@@ -53,7 +53,7 @@ def gemm_variant(request, built_lib):
     _hip.set_gemm_variant(0)
 
 
-@pytest.fixture(params=[1, 2, 32, 33], ids=lambda v: f"qg{v}")      # 32 / 33: the 32 x 32 x 16 kernel (pipelined / plain) where it applies
+@pytest.fixture(params=[1, 2, 4, 32, 33], ids=lambda v: f"qg{v}")      # 4: the key-split latency kernel; 32 / 33: the 32 x 32 x 16 kernel (pipelined / plain) where it applies
 def attn_qg(request, built_lib):
     from vall_e.vall_e import _hip
     _hip.set_attn_query_groups(request.param)
@@ -242,7 +242,7 @@ def test_attention_running_reference_moves_late(built_lib, dtype):
     ref = torch_attention(q, k, v, H, scale)
     bound = 2.0 * (_hip.op_attention(q, k, v, H, scale, family=_hip.FAMILY_GENERIC).float() - ref).abs().max().item()
     try:
-        for qg in (2, 32, 33):
+        for qg in (2, 4, 32, 33):
             _hip.set_attn_query_groups(qg)
             o = _hip.op_attention(q, k, v, H, scale).float()
             assert torch.isfinite(o).all()
@@ -494,9 +494,39 @@ def test_sample_loop_is_the_same_with_and_without_row_panel_launches(built_lib):
             _hip.set_row_panel(maskbits)
             outs.append(m.generate_audio(texts, proms, steps=3, seed=4).clone())
     finally:
-        _hip.set_row_panel(3)
+        _hip.set_row_panel(11)
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("batch", [1, 2])
+def test_dual_out_projection_of_the_latency_regime_is_bit_identical(built_lib, dtype, batch):
+    """row_panel bit 8: at one or two utterances both cross-attention out-projections run as ONE launch of the latency GEMM (two
+    products through one resident weight panel).  Hidden state and logits of a denoise step and the ids of a short loop must be
+    the bits of the two-launch form."""
+    from vall_e.vall_e import AR, _hip, synth
+    cfg = synth.D3PMConfig.libritts()
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0))
+    m = m.to(dtype).to(DEV)
+    smp = m.sampler()
+    texts, proms = synth.make_inputs(cfg, batch, 3)
+    ct, cp = m.encode_conditions(texts, proms)
+    kv_t, kv_p = smp.cond_kv(ct, cp)
+    x, fm = m.canvas_init(batch)
+    x[:, ::2] = torch.randint(0, 1024, x[:, ::2].shape, device=x.device, dtype=x.dtype)
+    outs = []
+    try:
+        for maskbits in (3, 11):
+            _hip.set_row_panel(maskbits)
+            lg, hid = smp.denoise(x, fm, 30, kv_t, kv_p, want_hidden=True)
+            ids = m.generate_audio(texts, proms, steps=3, seed=4)
+            outs.append((lg.clone(), hid.clone(), ids.clone()))
+    finally:
+        _hip.set_row_panel(11)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
 
 
 

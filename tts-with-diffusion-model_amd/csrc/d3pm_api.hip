@@ -379,6 +379,13 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     const bool norm3_fused = (panel & 2) && row_panel_supported(dt, g, rp);
     if (norm3_fused) {
       D3PM_TRY(run_row_panel(cx, dt, g, rp, s));
+    } else if ((tune_of(sh.tuning).row_panel & 8) && !(flags & D3PM_FLAG_FORCE_GENERIC) && tune_of(sh.tuning).gemm_variant == 0 &&
+               panel64_dual_supported(dt, g, ws.att2)) {
+      // one or two utterances: both out-projections in ONE launch of the latency GEMM (the weight panel is resident in LDS; o_text
+      // stays in registers): x = (x + o_text) + o_prompt with the roundings of the two-launch form below
+      g.tune = cx.tune;
+      ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * 2.0 * g.M * g.N * g.K, es * (2.0 * g.M * g.K + static_cast<double>(g.N) * g.K + 2.0 * g.M * g.N));
+      D3PM_TRY(panel64_dual(dt, g, ws.att2, s));
     } else {
       // o_text -> h (free now); x = (x + o_text) + o_prompt, rounded at each add like the eager sum
       g = LinearArgs();

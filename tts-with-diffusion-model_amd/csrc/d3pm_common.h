@@ -27,14 +27,37 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
   return v;
 }
+// v[l] + v[l ^ 32] and v[l] + v[l ^ 16] without the LDS crossbar: v_permlane{32,16}_swap of two copies of v leaves one register
+// holding the even halves (rows) twice and the other the odd ones, and a + b is bit for bit b + a -- the butterfly step of
+// __shfl_xor(v, 32 / 16) at a few cycles instead of a ds_bpermute round trip (~120).  `s_nop 1`: VALU write -> permlane read.
+__device__ __forceinline__ float add_xor32(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float add_xor16(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+template <int CTRL> __device__ __forceinline__ float add_dpp(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 // the same sum with the butterfly walked from lane distance 1 up to 32.  The vectorised LayerNorms use this order: lane L
 // holds the 8-element chunk L of a 512-wide row, and the GEMM epilogue that normalises a finished row in place
 // (d3pm_mfma_gemm_big.hip, row-panel kernel) holds chunk 8 wave + 4 np + 2 (lane bit 4) + (lane bit 5) -- low chunk bits
 // inside a wave, high bits across waves -- so walking low to high lets it reproduce this tree exactly: same bits out.
+// Every step is v[l] + v[l ^ off] as with __shfl_xor, on the DPP / permlane paths instead of six ds_bpermute round trips (at one
+// utterance a LayerNorm launch is a chain of dependent latencies, and the two reductions were a quarter of it): off = 1, 2 are
+// quad permutes; after them the four lanes of a quad hold the same bits, so the lane off = 4 away may be ANY lane of the
+// neighbouring quad (row_half_mirror: l ^ 7) and likewise off = 8 any lane of the other half row (row_mirror: l ^ 15).
 __device__ __forceinline__ float wave_sum_up(float v) {
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) v += __shfl_xor(v, off, kWave);
-  return v;
+  v = add_dpp<0xB1>(v);    // quad_perm [1, 0, 3, 2]: l ^ 1
+  v = add_dpp<0x4E>(v);    // quad_perm [2, 3, 0, 1]: l ^ 2
+  v = add_dpp<0x141>(v);   // row_half_mirror
+  v = add_dpp<0x140>(v);   // row_mirror
+  v = add_xor16(v);
+  return add_xor32(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -30,6 +30,14 @@ __global__ __launch_bounds__(256) void layernorm_vec(const T* __restrict__ x, T*
     live = frame_mask[row % canvas] != 0;
     xr = x + static_cast<size_t>(id) * d;
   }
+  // d = 512: the per-column parameters are fetched beside the row, not behind the two reductions (at one utterance a launch is a
+  // chain of dependent round trips: this removes one of them; at throughput batches the launch is memory-bound either way)
+  [[maybe_unused]] Vec8<T> pw, pb, pw2, pb2, psc, psh;
+  if constexpr (CH == 1) {
+    pw = *reinterpret_cast<const Vec8<T>*>(w + lane * 8); pb = *reinterpret_cast<const Vec8<T>*>(b + lane * 8);
+    if (film) { psc = *reinterpret_cast<const Vec8<T>*>(film + lane * 8); psh = *reinterpret_cast<const Vec8<T>*>(film + d + lane * 8); }
+    if (y2) { pw2 = *reinterpret_cast<const Vec8<T>*>(w2 + lane * 8); pb2 = *reinterpret_cast<const Vec8<T>*>(b2 + lane * 8); }
+  }
   float v[CH][8];
   float s = 0.f;
 #pragma unroll
@@ -52,7 +60,9 @@ __global__ __launch_bounds__(256) void layernorm_vec(const T* __restrict__ x, T*
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int col = (c * 64 + lane) * 8;
-    Vec8<T> wv = *reinterpret_cast<const Vec8<T>*>(w + col), bv = *reinterpret_cast<const Vec8<T>*>(b + col), o;
+    Vec8<T> wv, bv, o;
+    if constexpr (CH == 1) { wv = pw; bv = pb; }
+    else { wv = *reinterpret_cast<const Vec8<T>*>(w + col); bv = *reinterpret_cast<const Vec8<T>*>(b + col); }
     float n[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -60,7 +70,9 @@ __global__ __launch_bounds__(256) void layernorm_vec(const T* __restrict__ x, T*
       o.v[i] = static_cast<T>(n[i] * static_cast<float>(wv.v[i]) + static_cast<float>(bv.v[i]));
     }
     if (film) {
-      Vec8<T> sc = *reinterpret_cast<const Vec8<T>*>(film + col), sh = *reinterpret_cast<const Vec8<T>*>(film + d + col);
+      Vec8<T> sc, sh;
+      if constexpr (CH == 1) { sc = psc; sh = psh; }
+      else { sc = *reinterpret_cast<const Vec8<T>*>(film + col); sh = *reinterpret_cast<const Vec8<T>*>(film + d + col); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float g = rn<T>(1.0f + static_cast<float>(sc.v[i]));
@@ -69,7 +81,9 @@ __global__ __launch_bounds__(256) void layernorm_vec(const T* __restrict__ x, T*
     }
     *reinterpret_cast<Vec8<T>*>(y + static_cast<size_t>(row) * d + col) = o;
     if (y2) {
-      Vec8<T> w2v = *reinterpret_cast<const Vec8<T>*>(w2 + col), b2v = *reinterpret_cast<const Vec8<T>*>(b2 + col), o2;
+      Vec8<T> w2v, b2v, o2;
+      if constexpr (CH == 1) { w2v = pw2; b2v = pb2; }
+      else { w2v = *reinterpret_cast<const Vec8<T>*>(w2 + col); b2v = *reinterpret_cast<const Vec8<T>*>(b2 + col); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) o2.v[i] = static_cast<T>(n[i] * static_cast<float>(w2v.v[i]) + static_cast<float>(b2v.v[i]));
       *reinterpret_cast<Vec8<T>*>(y2 + static_cast<size_t>(row) * d + col) = o2;

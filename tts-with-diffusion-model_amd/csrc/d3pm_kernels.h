@@ -14,7 +14,7 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SILU = 3 };
 // The library has no mutable global state: the defaults are a constant.
 inline const d3pm_tuning& tune_of(const d3pm_tuning* t) {
   static const d3pm_tuning kDefault = {/*gemm_variant*/ 0, /*gemm_persist_slots*/ 1024, /*lat_tile*/ 0, /*attn_query_groups*/ 0,
-                                       /*attn_pair_sequential*/ 1, /*attn_cross_resident*/ 1, /*row_panel*/ 3, /*workspace_alias*/ 1,
+                                       /*attn_pair_sequential*/ 1, /*attn_cross_resident*/ 1, /*row_panel*/ 11, /*workspace_alias*/ 1,
                                        /*prof*/ nullptr};
   return t ? *t : kDefault;
 }
@@ -158,6 +158,9 @@ bool mfma_attention_supported(int dtype, const AttnArgs& a);
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s);
 bool mfma_attention32_supported(int dtype, const AttnArgs& a);   // d3pm_mfma_attn32.hip: self-attention on the 32 x 32 x 16 instruction
 int mfma_attention32(int dtype, const AttnArgs& a, hipStream_t s);
+// d3pm_mfma_attn_lat.hip: one or two utterances -- the key tiles of a 32-query group split over the four waves of a workgroup
+bool mfma_attention_split_supported(int dtype, const AttnArgs& a);
+int mfma_attention_split(int dtype, const AttnArgs& a, hipStream_t s);
 #ifdef D3PM_ABLATIONS
 int read_attn32_stamps(unsigned long long* out, int n);
 #endif
@@ -166,6 +169,9 @@ bool panel64_ln_supported(int dtype, const LinearArgs& a, const LnPrologue& ln);
 bool ln_prologue_linear_applies(int dtype, const LinearArgs& a, const LnPrologue& ln);   // would mfma_linear pick the latency GEMM?
 int ln_prologue_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, hipStream_t s);
 #endif
+// latency GEMM, two products through one weight panel: Y = rn(rn(R1 + rn(X W^T + b)) + rn(X2 W^T + b)) (d3pm_mfma_gemm_lat.hip)
+bool panel64_dual_supported(int dtype, const LinearArgs& a, const void* X2);
+int panel64_dual(int dtype, const LinearArgs& a, const void* X2, hipStream_t s);
 bool row_panel_supported(int dtype, const LinearArgs& a, const RowPanelFuse& f);
 int row_panel_linear(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s);
 bool fast_layernorm_supported(int dtype, const LayerNormArgs& a);

@@ -399,8 +399,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
 #pragma unroll
           for (int mt = 0; mt < 6; ++mt) {
             float a0 = part[mt][0], a1 = part[mt][1];
-            a0 += __shfl_xor(a0, 32, kWave); a1 += __shfl_xor(a1, 32, kWave);
-            a0 += __shfl_xor(a0, 16, kWave); a1 += __shfl_xor(a1, 16, kWave);
+            a0 = add_xor32(a0); a1 = add_xor32(a1);         // v[l] + v[l ^ 32], then ^ 16 (d3pm_common.h: same bits as __shfl_xor)
+            a0 = add_xor16(a0); a1 = add_xor16(a1);
             const float w8 = a0 + a1;
             if (g == 0) red[(which * 96 + mt * 16 + (lane & 15)) * 8 + wave] = w8;
           }

@@ -21,6 +21,11 @@
 //     8-element chunk L of a row, exactly layernorm_vec's layout, same arithmetic and reduction order, same bits -- before the
 //     MFMAs start.  Every column tile of a row block redoes the rows' LayerNorm (8 .. 32 x redundant, ~1 us), which at one
 //     utterance is far cheaper than the separate launch it removes: 18 of the 67 launches of a diffusion iteration.
+//   * two products through one weight panel (DUAL, K = d_model = 512, 32 x 64 tiles): the text and prompt cross-attention outputs
+//     both go through cross_attn.out_proj (ar_discrete.py:138,142).  The tile's W panel is in LDS for the whole kernel anyway, so
+//     the second operand's panel (X2, 32 KiB) rides in beside it and a second pass of the same k-steps gives
+//     x' = rn(rn(R1 + rn(X W^T + b)) + rn(X2 W^T + b)) -- the R1 + R2 epilogue of the two-launch form with R2 taken from
+//     registers: same bits, one launch (and one round trip of the intermediate through HBM) less per DiT block.
 #include "d3pm_kernels.h"
 #include "d3pm_mfma_tile.h"
 
@@ -49,14 +54,16 @@ template <typename T> struct LnProArgs {
   const T* w; const T* b; const T* w2; const T* b2; const T* film; float eps; int period;
 };
 
-template <typename T, int EPI, bool LNPRO = false, int TM = 64, int TN = 64>
+template <typename T, int EPI, bool LNPRO = false, int TM = 64, int TN = 64, bool DUAL = false>
 __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                             const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                             const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                             int mask_period, int M, int N, int K, int n_tiles,
-                                                            const uint16_t* __restrict__ gelu_tab_g, LnProArgs<T> ln) {
+                                                            const uint16_t* __restrict__ gelu_tab_g, LnProArgs<T> ln,
+                                                            const T* __restrict__ X2 = nullptr) {
   using G = LatGeom<TM, TN>;
   static_assert(!LNPRO || (TM == 64 && TN == 64), "the LayerNorm prologue is written for the base geometry");
+  static_assert(!DUAL || (!LNPRO && EPI == EPI_R1 && TN == 64), "two products: whole tiles, K = 2 rounds, x' = (R1 + h) + y2");
   static_assert(TM % 32 == 0 && TN % 64 == 0, "four waves as 2 x 2, column blocks regrouped in pairs");
   constexpr int XP = TM / 32, WP = TN / 32;       // DMA pieces (8 rows) per wave and sub-tile = MFMA row / column blocks per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -95,7 +102,18 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
     nr = nr < N ? nr : N - 1;
     gw[i] = W + static_cast<size_t>(nr) * K + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
   }
+  // the epilogue's operands (bias, residuals, frame mask) are requested FIRST: they are older than every DMA piece, so the
+  // counted waits below cover them, and they have landed long before the last MFMA instead of starting a new round trip there
+  EpiPre<T, WP, XP> pre;
+  if constexpr (!DUAL) epilogue_prefetch<T, EPI, WP, XP>(pre, bias, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * (TM / 2), n0 + wn * (TN / 2), lane);
+  [[maybe_unused]] Pack8<T> dual_r1;
+  [[maybe_unused]] EpiPre<T, WP, XP> dual_pre;
+  if constexpr (DUAL) {
+    epilogue_prefetch<T, 0, WP, XP>(dual_pre, bias, nullptr, nullptr, ldr, nullptr, 1, M, N, m0 + wm * (TM / 2), n0 + wn * (TN / 2), lane);
+    dual_r1 = *reinterpret_cast<const Pack8<T>*>(R1 + static_cast<size_t>(m0 + wm * (TM / 2) + (lane & 15)) * ldr + n0 + wn * (TN / 2) + epilogue_nq(lane));
+  }
   constexpr int PIECES = (KC / BK) * (XP + WP);       // per wave and round
+  constexpr int PIECES2 = DUAL ? 2 * (KC / BK) * XP : 0;   // the second operand's panel (both rounds), issued last
   auto issue_round = [&](int r, int buf) {
     const uint32_t base = lds_base + buf * G::BUF;
 #pragma unroll
@@ -115,6 +133,18 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
   const int rounds = K / KC;                 // K is a multiple of 256 (launcher)
   issue_round(0, 0);
   if (rounds > 1) issue_round(1, 1);
+  if constexpr (DUAL) {                      // K = 2 rounds (launcher): X2's whole-K panel behind the two buffers
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int s = 0; s < KC / BK; ++s)
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+          const int row = 8 * (wave + 4 * i) + lrow;       // whole tiles (launcher): no clamp
+          glds16_asm(X2 + static_cast<size_t>(m0 + row) * ldx + ((lane & 7) ^ ((row >> 1) & 7)) * 8 + r * KC + s * BK,
+                     lds_base + 2 * G::BUF + r * G::XOPER + s * G::XSUB + (wave + 4 * i) * 1024);
+        }
+  }
   if constexpr (LNPRO) {                     // K = 512: both rounds are the whole rows
     const bool second = ln.period && m0 >= ln.period;
     const T* lw = second ? ln.w2 : ln.w;
@@ -153,14 +183,8 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  for (int r = 0; r < rounds; ++r) {
-    const int buf = r & 1;
-    if (r + 1 < rounds) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");   // the next round's pieces may stay in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // every wave's pieces of round r have landed (LNPRO: and every row is normalised)
-    __builtin_amdgcn_sched_barrier(0);
-    const char* bx = smem + buf * G::BUF;
-    const char* bw = bx + G::XOPER;
+  // the four k-steps of one round: X sub-tiles at bx, W sub-tiles at bw
+  auto round_product = [&](const char* bx, const char* bw) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < KC / BK; ++s)
 #pragma unroll
@@ -175,6 +199,15 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
 #pragma unroll
           for (int mt = 0; mt < XP; ++mt) acc[nt][mt] = mma<T>(fw[nt], fx[mt], acc[nt][mt]);
       }
+  };
+  for (int r = 0; r < rounds; ++r) {
+    const int buf = r & 1;
+    if (r + 1 < rounds) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + PIECES2) : "memory");   // the next round's pieces may stay in flight
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES2) : "memory");
+    __builtin_amdgcn_s_barrier();            // every wave's pieces of round r have landed (LNPRO: and every row is normalised)
+    __builtin_amdgcn_sched_barrier(0);
+    const char* bx = smem + buf * G::BUF;
+    round_product(bx, bx + G::XOPER);
     __builtin_amdgcn_sched_barrier(0);
     if (r + 2 < rounds) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -182,8 +215,33 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
       issue_round(r + 2, buf);
     }
   }
-  epilogue_store<T, EPI, WP, XP>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * (TM / 2), n0 + wn * (TN / 2), lane,
-                                 nullptr, gelu_tab);
+  if constexpr (DUAL) {
+    // h = rn(X W^T + b) packed in registers, then the second product over the same W panel (both rounds are still in LDS)
+    static_assert(XP == 1 && WP == 2, "32 x 64 tiles: one 16-byte group per lane");
+    uintx4 h1p[1], y2p[1];
+    epilogue_store<T, 0, WP, XP, true, true, false, true>(acc, bias, Y, ldy, nullptr, nullptr, ldr, nullptr, 1, M, N, m0 + wm * (TM / 2), n0 + wn * (TN / 2), lane, h1p, nullptr, &dual_pre);
+#pragma unroll
+    for (int a = 0; a < WP; ++a)
+#pragma unroll
+      for (int b = 0; b < XP; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // every wave's X2 pieces have landed
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) round_product(smem + 2 * G::BUF + r * G::XOPER, smem + r * G::BUF + G::XOPER);
+    __builtin_amdgcn_sched_barrier(0);
+    epilogue_store<T, 0, WP, XP, true, true, false, true>(acc, bias, Y, ldy, nullptr, nullptr, ldr, nullptr, 1, M, N, m0 + wm * (TM / 2), n0 + wn * (TN / 2), lane, y2p, nullptr, &dual_pre);
+    // x' = rn(rn(R1 + h) + y2): the R1 + R2 epilogue of the two-launch form with R2 = h from registers
+    const Pack8<T> r1 = dual_r1;
+    const Pack8<T> hh = __builtin_bit_cast(Pack8<T>, h1p[0]), yy = __builtin_bit_cast(Pack8<T>, y2p[0]);
+    Pack8<T> o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = static_cast<T>(rn<T>(static_cast<float>(r1.v[i]) + static_cast<float>(hh.v[i])) + static_cast<float>(yy.v[i]));
+    *reinterpret_cast<Pack8<T>*>(Y + static_cast<size_t>(m0 + wm * (TM / 2) + (lane & 15)) * ldy + n0 + wn * (TN / 2) + epilogue_nq(lane)) = o;
+    return;
+  }
+  epilogue_store<T, EPI, WP, XP, false, false, false, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * (TM / 2),
+                                                            n0 + wn * (TN / 2), lane, nullptr, gelu_tab, &pre);
 }
 
 inline bool aligned16l(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
@@ -261,6 +319,35 @@ template <typename U, int E> static int panel64_geometry(const LinearArgs& a, co
     case 2: return panel64_launch<U, E, false, 32, 64>(a, nullptr, tab, s);
     default: return panel64_launch<U, E, false, 64, 64>(a, nullptr, tab, s);
   }
+}
+
+// x' = rn(rn(R1 + rn(X W^T + b)) + rn(X2 W^T + b)) in one launch (the two cross-attention out-projections of a DiT block at one or
+// two utterances): whole 32 x 64 tiles, K = 512 (both operand panels and the weight panel resident: 128 KiB)
+bool panel64_dual_supported(int dtype, const LinearArgs& a, const void* X2) {
+  if (!panel64_linear_supported(dtype, a) || !X2 || !aligned16l(X2)) return false;
+  if (a.K != 2 * KC || a.M % 32 != 0 || a.N % 64 != 0 || a.M > 2048) return false;
+  return a.R1 && !a.R2 && !a.row_mask && a.act == ACT_NONE && a.bias;
+}
+
+int panel64_dual(int dtype, const LinearArgs& a, const void* X2, hipStream_t s) {
+  using G = LatGeom<32, 64>;
+  constexpr size_t lds = 2 * G::BUF + 2 * G::XOPER;
+  const int n_tiles = a.N / 64, m_tiles = a.M / 32;
+  auto go = [&](auto* tag) -> int {
+    using U = std::remove_pointer_t<decltype(tag)>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_panel64<U, EPI_R1, false, 32, 64, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_set = true;
+    }
+    gemm_mfma_panel64<U, EPI_R1, false, 32, 64, true><<<dim3(static_cast<unsigned>(n_tiles * m_tiles)), dim3(256), lds, s>>>(
+        static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
+        static_cast<const U*>(a.R1), nullptr, a.ldr, nullptr, 1, a.M, a.N, a.K, n_tiles, nullptr, LnProArgs<U>{}, static_cast<const U*>(X2));
+    D3PM_LAUNCH_CHECK();
+    return D3PM_OK;
+  };
+  return dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
 }
 
 int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s, const LnPrologue* lnp) {

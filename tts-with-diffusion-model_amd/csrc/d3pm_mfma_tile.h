@@ -105,11 +105,77 @@ __device__ __forceinline__ void swap_rows16(float& a, float& b) {
 // the caller stores group (mt, np) later at Y + (mw0 + (lane & 15) + 16 mt) * ldy + nw0 + epilogue_nq(lane) + 32 np.
 __device__ __forceinline__ int epilogue_nq(int lane) { const int g = lane >> 4; return (g & 1) * 16 + (g >> 1) * 8; }
 
-template <typename T, int EPI, int NT = 4, int MT = 4, bool kInteriorOnly = false, bool kPack = false, bool kNts = false>
+// Operands of the epilogue fetched ahead of the main loop (latency GEMM: at one utterance a launch is a chain of dependent round
+// trips, and bias -> residual -> mask behind the last MFMA were three of them).  Addresses are clamped exactly as the loads inside
+// epilogue_store clamp them, so the prefetched values are the ones it would have loaded, for interior and ragged tiles alike:
+// same values, same arithmetic -- only when the loads are issued changes.
+template <typename T, int NT, int MT> struct EpiPre {
+  float bv[NT][4];
+  Pack8<T> r1[MT][NT / 2], r2[MT][NT / 2];
+  float mk[MT];
+};
+template <typename T, int EPI, int NT, int MT>
+__device__ __forceinline__ void epilogue_prefetch(EpiPre<T, NT, MT>& pre, const T* __restrict__ bias, const T* R1, const T* R2, int ldr,
+                                                  const uint8_t* __restrict__ row_mask, int mask_period, int M, int N, int mw0,
+                                                  int nw0, int lane) {
+  constexpr bool kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
+  constexpr int NP = NT / 2;
+  const int g = lane >> 4, nq = (g & 1) * 16 + (g >> 1) * 8;
+  if (bias == nullptr) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre.bv[nt][r] = 0.f;
+  } else if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(bias) & 7) == 0) {
+    Pack4<T> pb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nw0 + nt * 16 + g * 4;
+      pb[nt] = *reinterpret_cast<const Pack4<T>*>(bias + (n < N ? n : N - 4));
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre.bv[nt][r] = static_cast<float>(pb[nt].v[r]);
+  } else {
+    T sb[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nw0 + nt * 16 + g * 4 + r;
+        sb[nt][r] = bias[n < N ? n : N - 1];
+      }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre.bv[nt][r] = static_cast<float>(sb[nt][r]);
+  }
+  const int n_last = N >= 8 ? N - 8 : 0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mw0 + mt * 16 + (lane & 15);
+    const int mc = m < M ? m : M - 1;
+    pre.mk[mt] = 1.f;
+    if constexpr (kMask) pre.mk[mt] = row_mask[mc % mask_period] ? 1.f : 0.f;
+    if constexpr (kR1) {
+#pragma unroll
+      for (int np = 0; np < NP; ++np) {
+        int nc = nw0 + np * 32 + nq;
+        nc = nc < n_last ? nc : n_last;
+        pre.r1[mt][np] = *reinterpret_cast<const Pack8<T>*>(R1 + static_cast<size_t>(mc) * ldr + nc);
+        if constexpr (kR2) pre.r2[mt][np] = *reinterpret_cast<const Pack8<T>*>(R2 + static_cast<size_t>(mc) * ldr + nc);
+      }
+    }
+  }
+}
+
+template <typename T, int EPI, int NT = 4, int MT = 4, bool kInteriorOnly = false, bool kPack = false, bool kNts = false, bool kPre = false>
 __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* __restrict__ bias, T* Y, int ldy,
                                                const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                int mask_period, int M, int N, int mw0, int nw0, int lane,
-                                               uintx4* packed = nullptr, const uint16_t* gelu_tab = nullptr) {
+                                               uintx4* packed = nullptr, const uint16_t* gelu_tab = nullptr,
+                                               const EpiPre<T, NT, MT>* pre = nullptr) {   // pre: read only when kPre
   static_assert(!kPack || kInteriorOnly, "packing to registers is for whole tiles");
   static_assert(NT % 2 == 0, "column blocks are regrouped in pairs");
   constexpr bool kGelu = EPI & EPI_GELU, kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
@@ -119,7 +185,12 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
   // bias in the MFMA layout (applied before the regrouping).  Loads are branch-free per lane -- clamped addresses,
   // one batch, one wait: per-element predicated loads compile to sixteen serialized L2 round trips.
   float bv[NT][4];
-  if (bias == nullptr) {
+  if constexpr (kPre) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[nt][r] = pre->bv[nt][r];
+  } else if (bias == nullptr) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -172,13 +243,20 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
     const T* r2 = kR2 ? R2 + static_cast<size_t>(m) * ldr + nw0 + nq : nullptr;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const float mk = kMask ? (row_mask[(m + mt * 16) % mask_period] ? 1.f : 0.f) : 1.f;
+      float mk = 1.f;
+      if constexpr (kPre) mk = pre->mk[mt];
+      else if constexpr (kMask) mk = row_mask[(m + mt * 16) % mask_period] ? 1.f : 0.f;
       Pack8<T> p1[NP], p2[NP];
       if (kR1) {
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
-          p1[np] = *reinterpret_cast<const Pack8<T>*>(r1 + np * 32);
-          if (kR2) p2[np] = *reinterpret_cast<const Pack8<T>*>(r2 + np * 32);
+          if constexpr (kPre) {
+            p1[np] = pre->r1[mt][np];
+            if (kR2) p2[np] = pre->r2[mt][np];
+          } else {
+            p1[np] = *reinterpret_cast<const Pack8<T>*>(r1 + np * 32);
+            if (kR2) p2[np] = *reinterpret_cast<const Pack8<T>*>(r2 + np * 32);
+          }
         }
       }
 #pragma unroll
@@ -211,15 +289,22 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mw0 + mt * 16 + (lane & 15);
     const int mc = m < M ? m : M - 1;
-    const float mk = kMask ? (row_mask[mc % mask_period] ? 1.f : 0.f) : 1.f;
+    float mk = 1.f;
+    if constexpr (kPre) mk = pre->mk[mt];
+    else if constexpr (kMask) mk = row_mask[mc % mask_period] ? 1.f : 0.f;
     Pack8<T> p1[NP], p2[NP];
     if (kR1) {   // N % 8 == 0 is guaranteed by mfma_linear_supported when a residual is given
 #pragma unroll
       for (int np = 0; np < NP; ++np) {
-        int nc = nw0 + np * 32 + nq;
-        nc = nc < n_last ? nc : n_last;
-        p1[np] = *reinterpret_cast<const Pack8<T>*>(R1 + static_cast<size_t>(mc) * ldr + nc);
-        if (kR2) p2[np] = *reinterpret_cast<const Pack8<T>*>(R2 + static_cast<size_t>(mc) * ldr + nc);
+        if constexpr (kPre) {
+          p1[np] = pre->r1[mt][np];
+          if (kR2) p2[np] = pre->r2[mt][np];
+        } else {
+          int nc = nw0 + np * 32 + nq;
+          nc = nc < n_last ? nc : n_last;
+          p1[np] = *reinterpret_cast<const Pack8<T>*>(R1 + static_cast<size_t>(mc) * ldr + nc);
+          if (kR2) p2[np] = *reinterpret_cast<const Pack8<T>*>(R2 + static_cast<size_t>(mc) * ldr + nc);
+        }
       }
     }
 #pragma unroll
