@@ -82,12 +82,12 @@ enum {
  *   attn_query_groups  schedule of the MFMA self-attention: 0 = auto -- the software-pipelined 32 x 32 x 16 kernel (one 32-query
  *                      group per wave, three workgroups per CU) for whole 128-query blocks and 64-key tiles once that grid has two
  *                      workgroups per CU, else the 16 x 16 x 32 kernel with 2 sixteen-query groups per wave when that still gives
- *                      >= 4 workgroups per CU, else 1 -- and at one or two utterances (batch * canvas <= 1536 rows, the regime of
- *                      the latency GEMM) the key-split kernel: four waves share 32 queries and each walks every fourth 64-key tile, the partial
- *                      softmax states combined at the end; 1 or 2 = the 16 x 16 x 32 kernel with that many groups; 4 = the
- *                      key-split kernel wherever it applies; 32 = the 32 x 32 x 16 kernel wherever it applies; 33 = as 32 without
- *                      the software pipeline.  (The schedules accumulate in different orders: results agree to rounding noise,
- *                      not bit for bit; within one schedule a result does not depend on the batch it rides in.)
+ *                      >= 4 workgroups per CU, else 1; 1 or 2 = the 16 x 16 x 32 kernel with that many groups; 4 = the key-split
+ *                      kernel (four waves share 32 queries and each walks every fourth 64-key tile, the partial softmax states
+ *                      combined at the end; measured 2 % faster at one utterance and slower from two on, so never automatic);
+ *                      32 = the 32 x 32 x 16 kernel wherever it applies; 33 = as 32 without the software pipeline.  (The schedules
+ *                      accumulate in different orders: results agree to rounding noise, not bit for bit; within one schedule a
+ *                      result does not depend on the batch it rides in.)
  *   attn_pair_sequential  a paired attention launch (text + prompt cross-attention) on the tile-by-tile kernel: 2 = every
  *                      workgroup runs both problems one after the other; 0 = the second half of the grid takes problem 2;
  *                      1 (default) = auto: sequential while that still leaves >= 2 workgroups per CU.

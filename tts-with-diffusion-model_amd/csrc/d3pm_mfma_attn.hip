@@ -728,15 +728,12 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     D3PM_LAUNCH_CHECK();
     return D3PM_OK;
   }
-  // One or two utterances: the key-split kernel of d3pm_mfma_attn_lat.hip (four waves share 32 queries and take every fourth key
-  // tile: a chain of three tiles instead of twelve for the 768-key self-attention, of one for the text / prompt pair) in the
-  // regime of the latency GEMM (batch * canvas <= 1536 rows: one or two utterances of 768 frames), so that the self- and the
-  // cross-attention of a block change schedule at the same batch size.  attn_query_groups: 0 auto, 4 wherever it applies, 1 / 2 never.
-  {
-    const int q = tn.attn_query_groups;
-    if ((q == 4 || (q == 0 && static_cast<long long>(a.B) * a.Tq <= 1536)) && mfma_attention_split_supported(dtype, a))
-      return mfma_attention_split(dtype, a, s);
-  }
+  // Opt-in (attn_query_groups = 4): the key-split kernel of d3pm_mfma_attn_lat.hip -- four waves share 32 queries and take every
+  // fourth key tile.  Measured at one utterance 0.8 ms of 38.8 faster (p50), at two utterances 2 ms slower (tests/ab_latency.py,
+  // profiles/round3_o_ab_latency.txt): the launch is bound by the K / V bytes each workgroup streams through its CU (196 KB per
+  // (head, query group) at 768 keys), not by the length of the tile chain, so it is not an automatic choice -- one utterance keeps
+  // the schedule, and therefore the bits, of the batches up to ten.
+  if (tn.attn_query_groups == 4 && mfma_attention_split_supported(dtype, a)) return mfma_attention_split(dtype, a, s);
   const long long wgs2 = static_cast<long long>((a.Tq + 127) / 128) * a.H * a.B * (a.Q2 ? 2 : 1);
   const int qg = g_attn_qg == 0 ? (wgs2 >= 4 * 256 ? 2 : 1) : g_attn_qg >= 100 ? 2 : (g_attn_qg == 3 && (dtype != D3PM_BF16 || a.Q2)) ? 2 : g_attn_qg, per_block = 64 * qg;
   const int n_qblocks = (a.Tq + per_block - 1) / per_block;
