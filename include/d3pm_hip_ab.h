@@ -18,7 +18,8 @@ extern "C" {
 
 /* D3PM_AB_GEMM_BIG_MODE  schedule of the big-tile GEMM: 1 (shipped) / 0 = hand-placed / compiler-placed fragment reads, 9 = the
  *                        output stores of a tile issued inside the next tile's k-steps, 513 = non-temporal output stores,
- *                        2049 = every DMA piece of a k-step issued at its top (all: same results, none faster).
+ *                        2049 = every DMA piece of a k-step issued at its top (all: same results, none faster); 32769 = the
+ *                        epilogue's operands (bias, residual rows, frame mask) requested at the top of the tile (same results).
  *                        TIMING-ONLY builds whose results are wrong by construction (parts of the kernel removed; bits:
  *                        16 no DMA, 32 no MFMA, 64 no barriers, 128 no LDS reads, 256 clock stamp for d3pm_debug_gemm_clock,
  *                        4096 with 32 = the operand stream through registers; 1025 = row panels without their LayerNorm

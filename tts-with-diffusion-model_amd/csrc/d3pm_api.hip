@@ -973,7 +973,7 @@ void d3pm_tuning_default(d3pm_tuning* t) {
 #ifdef D3PM_ABLATIONS
 int d3pm_ab_set(int knob, int value) {
   AbKnobs& k = ab_knobs();
-  static const int big_modes[] = {0, 1, 3, 5, 9, 17, 32, 33, 81, 145, 209, 257, 465, 513, 1025, 2049, 4129, 8193, 16385, 24577};
+  static const int big_modes[] = {0, 1, 3, 5, 9, 17, 32, 33, 81, 145, 209, 257, 465, 513, 1025, 2049, 4129, 8193, 16385, 24577, 32769};
   if (knob == D3PM_AB_GEMM_BIG_MODE) {
     for (int m : big_modes)
       if (m == value) { k.big_mode = value; return D3PM_OK; }

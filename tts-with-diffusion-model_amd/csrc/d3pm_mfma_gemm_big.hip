@@ -98,6 +98,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   constexpr int ABL = (MODE >> 4) & 3;
   constexpr bool kNoSync = (MODE & 64) != 0, kNoReads = (MODE & 128) != 0, kStamp = (MODE & 256) != 0;
   constexpr bool kPrioYoung = (MODE & 2) != 0, kPrioMfma = (MODE & 4) != 0, kDrip = (MODE & 8) != 0;
+  // MODE bit 15: the epilogue's operands (bias, residual rows, frame mask) of a tile are requested at the top of the tile instead
+  // of behind its last MFMA -- one exposed round trip less per tile, and for one-round launches (fc2: one tile per CU) the 25 MB
+  // residual read runs under the k-loop instead of after it.  NPRE = the vector-memory operations this certainly adds behind
+  // the previous tile's stores (a LOWER bound keeps the counted waits safe: they may only wait for more): 12 residual + 6 mask loads
+  constexpr bool kPreEpi = (MODE & 32768) != 0 && FUSE == 0 && (EPI & EPI_R2) == 0;
+  constexpr int NPRE = !kPreEpi ? 0 : ((EPI & EPI_R1) ? 12 : 0) + ((EPI & EPI_MASK) ? 6 : 0);
+  static_assert((MODE & 32768) == 0 || (!kDrip && (MODE & 1)), "epilogue prefetch rides in the hand-placed schedule");
   constexpr bool kDual = (FUSE & FUSE_DUAL) != 0, kLn = (FUSE & FUSE_LN) != 0, kLn2 = (FUSE & FUSE_LN2) != 0, kFilm = (FUSE & FUSE_FILM) != 0;
   constexpr bool kMx = (FUSE & FUSE_MX) != 0;
   static_assert(!kMx || kLn, "the MX output is the LayerNorm output");
@@ -185,6 +192,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
 #pragma unroll
       for (int b = 0; b < 6; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
     const int m0 = (tile / n_tiles) * TM, n0 = (tile % n_tiles) * TN;
+    [[maybe_unused]] EpiPre<T, 4, 6> pre;
+    if constexpr (kPreEpi) epilogue_prefetch<T, EPI, 4, 6>(pre, bias, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96, n0 + wn * 64, lane);
     // what follows this tile (block-uniform); the last tile re-reads its own first k-step: valid memory, never used
     const int t_next = t + per_xcd;
     const bool more = t_next < cnt;
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
         }
       }
     } else {
-      run_k(sx, sx_next, sw_next, std::integral_constant<int, 12>{});
+      run_k(sx, sx_next, sw_next, std::integral_constant<int, 12 + NPRE>{});
     }
     if constexpr (FUSE != 0) {
       uintx4 xp[12];
@@ -524,8 +533,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
       pend_y = Y + static_cast<size_t>(m0 + wm * 96 + (lane & 15)) * ldy + n0 + wn * 64 + epilogue_nq(lane);
       pending = true;
     } else {
-      epilogue_store<T, EPI, 4, 6, true, false, (MODE & 512) != 0>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
-                                                                   n0 + wn * 64, lane, nullptr, gelu_tab);
+      epilogue_store<T, EPI, 4, 6, true, false, (MODE & 512) != 0, kPreEpi>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
+                                                                            n0 + wn * 64, lane, nullptr, gelu_tab, &pre);
     }
     if (!more) break;
     t = t_next;
@@ -676,6 +685,11 @@ static int big_launch_geometry(int id, const LinearArgs& a, int n_tiles, int til
     if (id == 2 && md == 8193) return big_launch<U, E, 2, 4, 8193>(a, n_tiles, tiles_total, grid, lds, s);
     if (id == 2 && md == 16385) return big_launch<U, E, 2, 4, 16385>(a, n_tiles, tiles_total, grid, lds, s);
     if (id == 2 && md == 24577) return big_launch<U, E, 2, 4, 24577>(a, n_tiles, tiles_total, grid, lds, s);
+  }
+  if (md == 32769) {    // A/B: epilogue operands prefetched at the top of the tile (tests/ab_gemm.py)
+    if (id == 1) return big_launch<U, E, 1, 8, 32769>(a, n_tiles, tiles_total, grid, lds, s);
+    if (id == 2) return big_launch<U, E, 2, 4, 32769>(a, n_tiles, tiles_total, grid, lds, s);
+    return big_launch<U, E, 2, 2, 32769>(a, n_tiles, tiles_total, grid, lds, s);
   }
   if (md == 513) {      // hand-placed schedule with non-temporal output stores (A/B: tests/ab_gemm.py)
     if (id == 1) return big_launch<U, E, 1, 8, 513>(a, n_tiles, tiles_total, grid, lds, s);
