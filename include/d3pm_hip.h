@@ -41,7 +41,9 @@ extern "C" {
  *    the library keeps no mutable global state besides the thread-local error string.  The experiment-only entry points
  *    (d3pm_set_tuning's ablation arms, d3pm_op_final_sample, d3pm_op_linear_lnpro, d3pm_debug_gemm_clock) left the product:
  *    they live in libd3pm_hip_ab.so, include/d3pm_hip_ab.h. */
-#define D3PM_ABI_VERSION 4
+/* 5: + d3pm_op_attention_pair; new VALUES of existing tuning fields (row_panel bit 3, attn_query_groups 4, attn_cross_resident
+ *    4 / 5); layouts unchanged */
+#define D3PM_ABI_VERSION 5
 
 enum { D3PM_F32 = 0, D3PM_F16 = 1, D3PM_BF16 = 2 };
 
@@ -94,7 +96,10 @@ enum {
  *   attn_cross_resident  the cross-attention pair of a block (<= 64 and <= 256 keys) with every K / V tile of both problems
  *                      fetched into LDS once per (utterance, head) by a workgroup of eight waves that then walks that head's
  *                      256-query blocks: 2 = always, 0 = never (tile-by-tile kernel), 1 (default) = auto: when there is at least
- *                      one such workgroup per CU (batch >= 11 at 768 rows and 8 heads); 3 = as 2 with one query block per workgroup.
+ *                      one such workgroup per CU (batch >= 11 at 768 rows and 8 heads); 3 = as 2 with one query block per workgroup;
+ *                      4 / 5 = as 2 on the 16 x 16 x 32 / the 32 x 32 x 16 instruction.  The resident kernel of 1 / 2 / 3 is the
+ *                      32 x 32 x 16 one (the software-pipelined 32-key block of the self-attention kernel); the 16 x 16 x 32 form
+ *                      (4) is bit-identical to the tile-by-tile kernel, the two instruction shapes accumulate in different orders.
  *   row_panel          bit mask of the block's projections that run as row-panel launches (d3pm_op_linear_rowpanel) when
  *                      d_model = 512, the dtype is 16-bit and batch * canvas is a multiple of 96: 1 = self-attention
  *                      out-projection + norm2 | norm22, 2 = both cross-attention out-projections + norm3 / FiLM, 4 = fc2 + the
@@ -387,6 +392,12 @@ int d3pm_op_linear_mx(int out_dtype, const void *X8, int ldx, const void *SX, co
 int d3pm_op_attention(int dtype, int family, const void *Q, int ldq, const void *K, const void *V, int ldkv,
                       void *O, int ldo, int B, int Tq, int S, int H, int hd, float scale, const d3pm_tuning *tuning,
                       void *stream);
+/* The text and prompt cross-attentions of a DiT block (ar_discrete.py:138,142) as the block launches them: two independent
+ * problems with the same B / Tq / H / hd -- queries Q1 / Q2 [B][Tq][ldq], keys and values K / V [B][S][ldkv] with S1 / S2 keys,
+ * outputs O1 / O2 [B][Tq][ldo] -- in ONE launch (tuning->attn_cross_resident / attn_pair_sequential pick the schedule). */
+int d3pm_op_attention_pair(int dtype, const void *Q1, const void *K1, const void *V1, void *O1, int S1, const void *Q2,
+                           const void *K2, const void *V2, void *O2, int S2, int ldq, int ldkv, int ldo, int B, int Tq, int H,
+                           int hd, float scale, const d3pm_tuning *tuning, void *stream);
 int d3pm_op_layernorm(int dtype, const void *X, void *Y, const void *w, const void *b, const void *film,
                       int M, int d, float eps, void *stream);
 /* Row-panel projection (d_model = 512): a Linear whose output is added to the residual stream, together with the LayerNorm(s)

@@ -224,6 +224,37 @@ def test_attention_mfma_vs_generic_vs_torch(attn_qg, dtype, Tq, S):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("resident", [0, 4, 5], ids=["tile_by_tile", "resident16", "resident32"])
+@pytest.mark.parametrize("Tq,S1,S2", [(768, 50, 225), (448, 50, 200), (384, 64, 256), (300, 1, 33), (768, 33, 97), (256, 32, 1), (512, 17, 160)])
+def test_attention_pair_vs_torch(built_lib, dtype, resident, Tq, S1, S2):
+    """The text / prompt cross-attention pair of a block (d3pm_op_attention_pair) on every schedule -- tile by tile, both K / V
+    images resident on the 16 x 16 x 32 instruction, resident on the 32 x 32 x 16 instruction with the software-pipelined 32-key
+    block (key counts that end inside a block are masked through the product's C operand; blocks past the last key are not
+    walked) -- against torch fp32 on the same 16-bit inputs, K / V as views of packed cache rows."""
+    from vall_e.vall_e import _hip
+    B, H, hd = 3, 8, 64
+    d = H * hd
+    g = torch.Generator(device="cpu").manual_seed(Tq * 7 + S1 * 3 + S2)
+    q1 = torch.randn(B, Tq, d, generator=g).to(dtype).to(DEV)
+    q2 = torch.randn(B, Tq, d, generator=g).to(dtype).to(DEV)
+    kv1 = (1.5 * torch.randn(B, S1, 2 * d, generator=g)).to(dtype).to(DEV)
+    kv2 = (1.5 * torch.randn(B, S2, 2 * d, generator=g)).to(dtype).to(DEV)
+    scale = math.sqrt(1.0 / hd)
+    ref1 = torch_attention(q1, kv1[..., :d], kv1[..., d:], H, scale)
+    ref2 = torch_attention(q2, kv2[..., :d], kv2[..., d:], H, scale)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    try:
+        _hip.set_attn_cross_resident(resident)
+        o1, o2 = _hip.op_attention_pair(q1, kv1[..., :d], kv1[..., d:], q2, kv2[..., :d], kv2[..., d:], H, scale)
+    finally:
+        _hip.set_attn_cross_resident(1)
+    for name, o, ref in (("text", o1, ref1), ("prompt", o2, ref2)):
+        assert torch.isfinite(o).all()
+        err = (o.float() - ref).abs().max().item()
+        assert err < tol, f"{name} problem Tq={Tq} S={S1}/{S2} resident={resident}: max abs err {err}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_attention_running_reference_moves_late(built_lib, dtype):
     """Scores that keep growing along the keys (and a burst in the last tile): the deferred running maximum of the flash kernels
     has to be raised in the middle of the walk -- in the pipelined 32 x 32 x 16 kernel that is the rare path behind P.V(j) and
@@ -397,8 +428,8 @@ def test_linear_mx_rejects_what_it_cannot_run(built_lib):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("config", ["libritts", "wide448"])
 def test_cross_attention_pair_resident_kernel_equals_the_tile_by_tile_kernel(built_lib, dtype, config):
-    """attn_cross_hd64 (all K / V tiles of the text and prompt problems resident in LDS) runs the per-tile arithmetic of
-    attn_mfma_hd64 in the same order: a denoise step must give the same hidden state and logits bit for bit, for whole
+    """attn_cross_hd64 (all K / V tiles of the text and prompt problems resident in LDS; attn_cross_resident = 4) runs the per-tile
+    arithmetic of attn_mfma_hd64 in the same order: a denoise step must give the same hidden state and logits bit for bit, for whole
     and ragged key tiles (50 / 225 keys; 50 / 398 keys does not fit and must fall back) and a canvas that is not a multiple
     of the 256-query block (448)."""
     from vall_e.vall_e import AR, _hip, synth
@@ -414,7 +445,7 @@ def test_cross_attention_pair_resident_kernel_equals_the_tile_by_tile_kernel(bui
     x[:, ::2] = torch.randint(0, 1024, x[:, ::2].shape, device=x.device, dtype=x.dtype)
     outs = []
     try:
-        for on in (False, True):
+        for on in (0, 4):                       # 4: resident on the 16 x 16 x 32 instruction (the 32 x 32 x 16 form accumulates in another order)
             _hip.set_attn_cross_resident(on)
             lg, hid = smp.denoise(x, fm, 30, kv_t, kv_p, want_hidden=True)
             outs.append((lg.clone(), hid.clone()))

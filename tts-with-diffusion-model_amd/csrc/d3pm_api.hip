@@ -896,6 +896,20 @@ int d3pm_op_attention(int dtype, int family, const void* Q, int ldq, const void*
   return run_attention(cx, dtype, a, 0, s);
 }
 
+int d3pm_op_attention_pair(int dtype, const void* Q1, const void* K1, const void* V1, void* O1, int S1, const void* Q2, const void* K2,
+                           const void* V2, void* O2, int S2, int ldq, int ldkv, int ldo, int B, int Tq, int H, int hd, float scale,
+                           const d3pm_tuning* tuning, void* stream) {
+  D3PM_REQUIRE(Q1 && K1 && V1 && O1 && Q2 && K2 && V2 && O2 && B > 0 && Tq > 0 && S1 > 0 && S2 > 0 && H > 0 && hd > 0, D3PM_E_ARG,
+               "d3pm_op_attention_pair: bad arguments");
+  const Ctx cx(tuning);
+  AttnArgs a;
+  a.tune = tuning;
+  a.Q = Q1; a.ldq = ldq; a.K = K1; a.V = V1; a.ldkv = ldkv; a.O = O1; a.ldo = ldo; a.B = B; a.Tq = Tq; a.S = S1; a.H = H;
+  a.hd = hd; a.scale = scale;
+  a.Q2 = Q2; a.K2 = K2; a.V2 = V2; a.O2 = O2; a.S2 = S2;
+  return run_attention(cx, dtype, a, 0, static_cast<hipStream_t>(stream));
+}
+
 int d3pm_op_layernorm(int dtype, const void* X, void* Y, const void* w, const void* b, const void* film, int M, int d,
                       float eps, void* stream) {
   D3PM_REQUIRE(X && Y && w && b && M > 0 && d > 0, D3PM_E_ARG, "d3pm_op_layernorm: bad arguments");

@@ -158,6 +158,8 @@ bool mfma_attention_supported(int dtype, const AttnArgs& a);
 int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s);
 bool mfma_attention32_supported(int dtype, const AttnArgs& a);   // d3pm_mfma_attn32.hip: self-attention on the 32 x 32 x 16 instruction
 int mfma_attention32(int dtype, const AttnArgs& a, hipStream_t s);
+bool mfma_attention32_cross_supported(int dtype, const AttnArgs& a);   // the resident cross-attention pair on the same instruction
+int mfma_attention32_cross(int dtype, const AttnArgs& a, int n_qsplit, hipStream_t s);
 // d3pm_mfma_attn_lat.hip: one or two utterances -- the key tiles of a 32-query group split over the four waves of a workgroup
 bool mfma_attention_split_supported(int dtype, const AttnArgs& a);
 int mfma_attention_split(int dtype, const AttnArgs& a, hipStream_t s);

@@ -75,6 +75,25 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2v){a, b}, pair));
 }
 
+// Output rows of the 16 x 16 kernels.  A lane holds, per 16-column block dt of its query's 64 output columns, columns
+// 16 dt + 4 g .. + 3 (g = lane >> 4): four 8-byte stores per query group, a tail bound by the number of store INSTRUCTIONS
+// (MI355X_MICROARCH.md, 'attention epilogue store tail').  v_permlane16_swap between the packed registers of blocks dt and dt + 1
+// (odd 16-lane rows of the first trade places with the even rows of the second -- the regrouping of the GEMM epilogue,
+// d3pm_mfma_tile.h) leaves a lane with 8 consecutive columns (dt + (g & 1)) 16 + (g >> 1) 8 .. + 7: two 16-byte stores, same
+// bytes, same addresses.  Every lane takes part in the swaps; only the store is predicated.
+template <typename T>
+__device__ __forceinline__ void store_rows16(T* row_base /* O + row * ldo + h * 64, 16-byte aligned */, const floatx4 (&acc)[4], float inv, int g,
+                                             bool live) {
+#pragma unroll
+  for (int dt = 0; dt < 4; dt += 2) {
+    uint32_t ax = pack2<T>(acc[dt][0] * inv, acc[dt][1] * inv), ay = pack2<T>(acc[dt][2] * inv, acc[dt][3] * inv);
+    uint32_t bx = pack2<T>(acc[dt + 1][0] * inv, acc[dt + 1][1] * inv), by = pack2<T>(acc[dt + 1][2] * inv, acc[dt + 1][3] * inv);
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ax), "+v"(bx));
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ay), "+v"(by));
+    if (live) *reinterpret_cast<uint4*>(row_base + (dt + (g & 1)) * 16 + (g >> 1) * 8) = uint4{ax, ay, bx, by};
+  }
+}
+
 // ABL != 0 is instantiated in the A/B library only (-DD3PM_ABLATIONS): timing-only ablation builds (results wrong by construction; tests/ab_attn.py): 1 no v_exp, 2 no maximum / rescale logic, 4 no K/V
 // staging after the first tile, 8 no barriers, 16 no P.V product, 32 no Q.K product
 // fragment reads whose completion is waited for by hand (ABL bit 6: every K and V fragment of a tile issued at the top of
@@ -412,14 +431,7 @@ __global__ __launch_bounds__(256, QG == 1 ? 4 : 2) void attn_mfma_hd64(const T* 
   for (int qg = 0; qg < QG; ++qg) {
     const float inv = 1.0f / acc_l[qg][0];
     const int qrow = q0 + qg * 16 + qi;
-    if (qrow < Tq) {
-      T* op = O + (static_cast<size_t>(b) * Tq + qrow) * ldo + h * HD;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        uint2 o{pack2<T>(acc_o[qg][dt][0] * inv, acc_o[qg][dt][1] * inv), pack2<T>(acc_o[qg][dt][2] * inv, acc_o[qg][dt][3] * inv)};
-        *reinterpret_cast<uint2*>(op + dt * 16 + 4 * g) = o;
-      }
-    }
+    store_rows16<T>(O + (static_cast<size_t>(b) * Tq + (qrow < Tq ? qrow : Tq - 1)) * ldo + h * HD, acc_o[qg], inv, g, qrow < Tq);
   }
   }   // problems of a sequential pair
 }
@@ -645,14 +657,7 @@ __global__ __launch_bounds__(512, 2) void attn_cross_hd64(const T* __restrict__ 
     for (int qg = 0; qg < QG; ++qg) {
       const float inv = 1.0f / acc_l[qg][0];
       const int qrow = q0 + qg * 16 + qi;
-      if (qrow < Tq) {
-        T* op = O + (static_cast<size_t>(b) * Tq + qrow) * ldo + h * HD;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          uint2 o{pack2<T>(acc_o[qg][dt][0] * inv, acc_o[qg][dt][1] * inv), pack2<T>(acc_o[qg][dt][2] * inv, acc_o[qg][dt][3] * inv)};
-          *reinterpret_cast<uint2*>(op + dt * 16 + 4 * g) = o;
-        }
-      }
+      store_rows16<T>(O + (static_cast<size_t>(b) * Tq + (qrow < Tq ? qrow : Tq - 1)) * ldo + h * HD, acc_o[qg], inv, g, qrow < Tq);
     }
   }
   }   // query blocks
@@ -666,9 +671,9 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 bool mfma_attention_supported(int dtype, const AttnArgs& a) {
   if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
   if (a.hd != HD || a.S < 1 || a.Tq < 1) return false;
-  if (a.ldq % 8 || a.ldkv % 8 || a.ldo % 4) return false;
-  if (a.Q2 && !(a.S2 >= 1 && aligned(a.Q2, 16) && aligned(a.K2, 16) && aligned(a.V2, 16) && aligned(a.O2, 8))) return false;
-  return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 8);
+  if (a.ldq % 8 || a.ldkv % 8 || a.ldo % 8) return false;      // 16-byte output stores
+  if (a.Q2 && !(a.S2 >= 1 && aligned(a.Q2, 16) && aligned(a.K2, 16) && aligned(a.V2, 16) && aligned(a.O2, 16))) return false;
+  return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 16);
 }
 
 // d3pm_tuning.attn_query_groups: 0 = auto: two 16-query groups per wave (each K / V fragment read from LDS feeds two MFMAs;
@@ -704,6 +709,13 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     int n_qsplit = (256 + a.H * a.B - 1) / (a.H * a.B);            // workgroups per (utterance, head): enough to cover the CUs
     n_qsplit = n_qsplit < 1 ? 1 : n_qsplit > n_qblocks ? n_qblocks : n_qsplit;
     if (g_attn_cross_resident == 3) n_qsplit = n_qblocks;              // tuning: one query block per workgroup (the first form)
+    // the same residency on the 32 x 32 x 16 instruction with the software-pipelined block of d3pm_mfma_attn32.hip (the shipped
+    // form: 34.9 vs 35.8 us per pair in the microbenchmark, 43.1 vs 44.1 us per attention launch in the loop, tests/ab_cross32.py,
+    // profiles/round3_r_ab_cross32.txt; it takes over at the batch size where the self-attention changes instruction shape too):
+    // 5 always, 4 = the 16 x 16 x 32 form (bit-identical to the tile-by-tile kernel)
+    constexpr bool kCross32 = true;
+    if ((g_attn_cross_resident == 5 || (kCross32 && g_attn_cross_resident != 4)) && mfma_attention32_cross_supported(dtype, a))
+      return mfma_attention32_cross(dtype, a, n_qsplit, s);
     const dim3 grid(static_cast<unsigned>(n_qsplit * a.H * a.B)), block(512);
     const size_t lds = static_cast<size_t>(1 + (a.S2 + BKV - 1) / BKV) * 2 * TILE;
 #define D3PM_CROSS(T, PIPE)                                                                                                  \

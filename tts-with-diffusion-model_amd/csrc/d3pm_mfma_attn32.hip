@@ -62,6 +62,26 @@ __device__ __forceinline__ void halves(float x, float& lo, float& hi) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
 }
 
+// Output rows of the 32 x 32 kernels.  A lane holds, per 8-column group k = 4 db + j of its query's 64 output columns, columns
+// 8 k + 4 hh .. + 3 (hh = lane >> 5): the natural store is eight 8-byte stores per lane, and that tail is bound by the number of
+// store INSTRUCTIONS, not by bytes (MI355X_MICROARCH.md, 'attention epilogue store tail').  v_permlane32_swap between the packed
+// registers of groups k and k + 1 (lanes 32-63 of the first trade places with lanes 0-31 of the second) leaves lanes 0-31 with
+// columns 8 k .. 8 k + 7 and lanes 32-63 with 8 k + 8 .. 8 k + 15: four 16-byte stores, same bytes, same addresses.
+template <typename T>
+__device__ __forceinline__ void store_rows32(T* row_base /* O + row * ldo + h * 64, 16-byte aligned */, const floatx16 (&acc)[2], float inv, int hh,
+                                             bool live) {
+  T* const p = row_base + (hh ? 8 : 0);
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    const int db = k >> 2, j = k & 3;
+    uint32_t ax = pack2<T>(acc[db][4 * j] * inv, acc[db][4 * j + 1] * inv), ay = pack2<T>(acc[db][4 * j + 2] * inv, acc[db][4 * j + 3] * inv);
+    uint32_t bx = pack2<T>(acc[db][4 * j + 4] * inv, acc[db][4 * j + 5] * inv), by = pack2<T>(acc[db][4 * j + 6] * inv, acc[db][4 * j + 7] * inv);
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ax), "+v"(bx));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ay), "+v"(by));
+    if (live) *reinterpret_cast<uint4*>(p + 8 * k) = uint4{ax, ay, bx, by};
+  }
+}
+
 // STAMP (A/B library only): wave 0 of the first workgroup and of one in the middle of the grid records the shader clock at eight
 // points of every key tile (d3pm_debug_attn32_stamps); see the stamp() calls for the points
 constexpr int kStampTiles = 12, kStampPoints = 8;
@@ -245,14 +265,7 @@ __global__ __launch_bounds__(256, 2) void attn32_hd64(const T* __restrict__ Q, i
   float la, lc;
   halves(lsum, la, lc);
   const float inv = 1.0f / (la + lc);
-  T* op = O + (static_cast<size_t>(b) * Tq + q0 + qn) * ldo + h * HD + 4 * hh;
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint2 o{pack2<T>(acc_o[db][4 * j] * inv, acc_o[db][4 * j + 1] * inv), pack2<T>(acc_o[db][4 * j + 2] * inv, acc_o[db][4 * j + 3] * inv)};
-      *reinterpret_cast<uint2*>(op + 32 * db + 8 * j) = o;
-    }
+  store_rows32<T>(O + (static_cast<size_t>(b) * Tq + q0 + qn) * ldo + h * HD, acc_o, inv, hh, true);
   if constexpr (STAMP == 1) {
     if (tid == 0 && (blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 48) {
       unsigned long long* o = g_attn32_stamp + (blockIdx.x >> 5) * 4;
@@ -520,20 +533,258 @@ __global__ __launch_bounds__(256, 3) void attn32p_hd64(const T* __restrict__ Q, 
   float la, lc;
   halves((ls[0] + ls[1]) + (ls[2] + ls[3]), la, lc);
   const float inv = 1.0f / (la + lc);
-  T* op = O + (static_cast<size_t>(b) * Tq + q0 + qn) * ldo + h * HD + 4 * hh;
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint2 o{pack2<T>(acc_o[db][4 * j] * inv, acc_o[db][4 * j + 1] * inv), pack2<T>(acc_o[db][4 * j + 2] * inv, acc_o[db][4 * j + 3] * inv)};
-      *reinterpret_cast<uint2*>(op + 32 * db + 8 * j) = o;
-    }
+  store_rows32<T>(O + (static_cast<size_t>(b) * Tq + q0 + qn) * ldo + h * HD, acc_o, inv, hh, true);
   if constexpr (STAMP == 1) {
     if (tid == 0 && (blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 48) {
       unsigned long long* o = g_attn32_stamp + (blockIdx.x >> 5) * 4;
       o[0] = stamp_c; o[1] = __builtin_amdgcn_s_memtime(); o[2] = stamp_r; o[3] = __builtin_amdgcn_s_memrealtime();
     }
   }
+}
+
+// ---- the cross-attention pair of a block on the same instruction: attn32_cross_hd64 ------------------------------------------
+// attn_cross_hd64 (d3pm_mfma_attn.hip) keeps every K / V tile of the text (<= 64 keys) and prompt (<= 256 keys) problems of one
+// (utterance, head) in LDS and walks that head's 256-query blocks with no barrier; what its launch then waits for is the issue
+// port of each SIMD (16 x 16 x 32: ~1300 issue cycles per 64-key tile and wave, matrix and vector work adding up).  This kernel
+// is that residency with the software-pipelined 32-key block of attn32p_hd64: a wave owns 32 queries, the products of block
+// j + 1 and the exponentials of block j share one instruction stream.  Differences from the self-attention kernel: no staging
+// and no barrier inside the walk (the image is resident), key counts that are not multiples of 32 -- the LAST block's product
+// starts from -m_ref on its valid keys and from -inf on the others (cmask: the C operand does the masking, no select in the
+// stream), blocks past the last valid key are not walked -- and two problems per query block with the next phase's queries
+// fetched under the current one.  K swizzle as attn_cross_hd64; V swizzle ((row >> 1) & 1) << 2 as attn32p_hd64 reads it.
+typedef const __attribute__((address_space(1))) void* glb_ptr32_t;
+typedef __attribute__((address_space(3))) void* lds_ptr32_t;
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void attn32_cross_hd64(const T* __restrict__ Q1, const T* __restrict__ K1, const T* __restrict__ V1,
+                                                            T* __restrict__ O1, int S1, const T* __restrict__ Q2,
+                                                            const T* __restrict__ K2, const T* __restrict__ V2, T* __restrict__ O2,
+                                                            int S2, int ldq, int ldkv, int ldo, int Tq, float scale, int H,
+                                                            int n_qblocks, int n_qsplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem_x[];   // [tile][K | V], 16 KiB per tile: tile 0 = text, 1.. = prompt
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid;
+  {
+    const int nblocks = gridDim.x, q = nblocks >> 3, r = nblocks & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int qs = bid % n_qsplit, h = (bid / n_qsplit) % H, b = bid / (n_qsplit * H);
+  const int nt2 = (S2 + BKV - 1) / BKV, n_tiles = 1 + nt2;
+  {   // every K / V piece of both problems: 16 pieces (1 KiB = 8 rows x 128 B) per tile, dealt over the 8 waves
+    const int lrow = lane >> 3, cpos = lane & 7;
+    const int total = n_tiles * 16;
+    for (int p = wave; p < total; p += 8) {                 // wave-uniform trip count
+      const int tile = p >> 4, which = (p >> 3) & 1, j = p & 7;   // which: 0 = K, 1 = V
+      const int row = 8 * j + lrow;
+      const int logical = which == 0 ? (cpos ^ ((row >> 1) & 7)) : (cpos ^ (((row >> 1) & 1) << 2));
+      const T* base = tile == 0 ? (which == 0 ? K1 : V1) : (which == 0 ? K2 : V2);
+      const int S = tile == 0 ? S1 : S2;
+      int key = (tile == 0 ? 0 : (tile - 1) * BKV) + row;
+      key = key < S ? key : S - 1;
+      const T* src = base + (static_cast<size_t>(b) * S + key) * ldkv + h * HD + logical * 8;
+      __builtin_amdgcn_global_load_lds((glb_ptr32_t)src, (lds_ptr32_t)(smem_x + tile * 2 * TILE + which * TILE + j * 1024), 16, 0, 0);
+    }
+  }
+  const int qn = lane & 31, hh = lane >> 5;
+  const float qscale = scale * 1.4426950408889634f;
+  int ok[4], ov[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) ok[ks] = k_off(qn, 2 * ks + hh);
+  {
+    const int qi = lane & 15, cb = (lane >> 4) & 1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int col = 32 * db + 16 * cb + 4 * (qi & 3);
+      ov[db] = v_off(4 * hh + (qi >> 2), col >> 3) + (col & 7) * 2;
+    }
+  }
+  uint4 qraw[4];
+  auto fetch_q = [&](int qb, int prob) __attribute__((always_inline)) {
+    const T* Q = prob == 0 ? Q1 : Q2;
+    int qrow = (qb * 8 + wave) * 32 + qn;
+    qrow = qrow < Tq ? qrow : Tq - 1;
+    const T* qp = Q + (static_cast<size_t>(b) * Tq + qrow) * ldq + h * HD + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qraw[ks] = *reinterpret_cast<const uint4*>(qp + ks * 16);
+  };
+  fetch_q(qs, 0);
+  bool landed = false;
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  for (int qb = qs; qb < n_qblocks; qb += n_qsplit) {
+  for (int prob = 0; prob < 2; ++prob) {
+    T* O = prob == 0 ? O1 : O2;
+    const int S = prob == 0 ? S1 : S2, t0 = prob == 0 ? 0 : 1;
+    const int nb = (S + 31) >> 5;                            // 32-key blocks with at least one valid key
+    const char* const pbase = smem_x + t0 * 2 * TILE;        // block j: K rows at pbase + (j >> 1) * 2 TILE + (j & 1) * 32 rows, V + TILE
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      typedef T tvec8 __attribute__((ext_vector_type(8)));
+      const tvec8 e = __builtin_bit_cast(tvec8, qraw[ks]);
+      qf[ks] = uint4{pack2<T>(static_cast<float>(e[0]) * qscale, static_cast<float>(e[1]) * qscale),
+                     pack2<T>(static_cast<float>(e[2]) * qscale, static_cast<float>(e[3]) * qscale),
+                     pack2<T>(static_cast<float>(e[4]) * qscale, static_cast<float>(e[5]) * qscale),
+                     pack2<T>(static_cast<float>(e[6]) * qscale, static_cast<float>(e[7]) * qscale)};
+    }
+    if (prob == 0) fetch_q(qb, 1);
+    else if (qb + n_qsplit < n_qblocks) fetch_q(qb + n_qsplit, 0);
+    if (!landed) {                                           // one wait for the whole workgroup's K / V image
+      __syncthreads();                                       // (drains this wave's DMA pieces, then the barrier)
+      landed = true;
+    }
+    // the last block's product starts from cmask - m_ref: 0 on its valid keys (lane: keys 8 j + 4 hh + r <-> element 4 j + r), -inf on the rest
+    floatx16 cmask, negm, acc_o[2], sA, sB;
+    {
+      const int lim = S - 32 * (nb - 1) - 4 * hh;            // this lane's key 8 j + r of the last block exists iff 8 j + r < lim
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cmask[i] = (8 * (i >> 2) + (i & 3) < lim) ? 0.f : -INFINITY;
+    }
+    float m_ref = 0.f;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { negm[i] = 0.f; acc_o[0][i] = 0.f; acc_o[1][i] = 0.f; }
+    uint4 kf[4];
+    auto kblock = [&](int j) __attribute__((always_inline)) -> const char* { return pbase + (j >> 1) * 2 * TILE + (j & 1) * 32 * ROWB; };
+    auto read_k = [&](const char* kb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(kb + ok[ks]);
+    };
+    auto row_max = [&](const floatx16& s) __attribute__((always_inline)) -> float {
+      float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+      for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s[i]), s[i + 1]);
+      return mx;
+    };
+    // ---- prologue: the scores of block 0 (masked if it is also the last one) and the first reference
+    read_k(kblock(0));
+    {
+      floatx16 c0 = negm;
+      if (nb == 1) c0 = cmask;                               // wave-uniform
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) sA = mma32<T>(kf[ks], qf[ks], ks == 0 ? c0 : sA);
+    }
+    if (nb > 1) read_k(kblock(1));
+    {
+      float a, c;
+      halves(row_max(sA), a, c);
+      const float delta = fmaxf(a, c);                       // finite: block 0 has a valid key
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sA[i] -= delta;
+      m_ref = delta;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[i] = -m_ref;
+    }
+    // one block (attn32p_hd64's, without staging): sc = S(j) relative to m_ref; NEXT: sn <- S(j + 1) from kf (K(j + 1), read by the
+    // previous block), LAST: that product is the last block's and starts from cmask - m_ref; READK: kf <- K(j + 2) from knext
+    auto block = [&](floatx16& sc, floatx16& sn, const char* vblock, const char* knext, auto NEXT_, auto LAST_, auto READK_)
+        __attribute__((always_inline)) {
+      constexpr bool NEXT = decltype(NEXT_)::value, LAST = decltype(LAST_)::value, READK = decltype(READK_)::value;
+      typedef short4v __attribute__((address_space(3))) * lds_ptr;
+      uint4 vf[2], pf;
+      auto read_v = [&](int t, int db) __attribute__((always_inline)) {
+        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vblock + ov[db] + (16 * t) * ROWB)));
+        const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vblock + ov[db] + (16 * t + 8) * ROWB)));
+        vf[db] = uint4{lo.x, lo.y, hi.x, hi.y};
+      };
+      auto e4 = [&](int i) __attribute__((always_inline)) {
+        sc[i] = __builtin_amdgcn_exp2f(sc[i]); sc[i + 1] = __builtin_amdgcn_exp2f(sc[i + 1]);
+        sc[i + 2] = __builtin_amdgcn_exp2f(sc[i + 2]); sc[i + 3] = __builtin_amdgcn_exp2f(sc[i + 3]);
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls[0]) : "v"(sc[i]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls[1]) : "v"(sc[i + 1]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls[2]) : "v"(sc[i + 2]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls[3]) : "v"(sc[i + 3]));
+      };
+      auto pack8 = [&](int i) __attribute__((always_inline)) {
+        pf = uint4{pack2<T>(sc[i], sc[i + 1]), pack2<T>(sc[i + 2], sc[i + 3]), pack2<T>(sc[i + 4], sc[i + 5]), pack2<T>(sc[i + 6], sc[i + 7])};
+      };
+      auto pv = [&](int db) __attribute__((always_inline)) { acc_o[db] = mma32<T>(vf[db], pf, acc_o[db]); };
+      floatx16 cn = negm;
+      if constexpr (NEXT && LAST) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cn[i] = negm[i] + cmask[i];
+      }
+      SB();
+      read_v(0, 0);
+      read_v(0, 1);
+      SB();
+      // ---- phase 1
+      if constexpr (NEXT) sn = mma32<T>(kf[0], qf[0], cn);
+      e4(0);
+      SB();
+      if constexpr (NEXT) sn = mma32<T>(kf[1], qf[1], sn);
+      e4(4);
+      SB();
+      if constexpr (NEXT) sn = mma32<T>(kf[2], qf[2], sn);
+      pack8(0);
+      SB();
+      if constexpr (NEXT) sn = mma32<T>(kf[3], qf[3], sn);
+      e4(8);
+      SB();
+      // ---- phase 2
+      pv(0);
+      read_v(1, 0);
+      e4(12);
+      SB();
+      pv(1);
+      read_v(1, 1);
+      if constexpr (READK) read_k(knext);
+      pack8(8);
+      SB();
+      pv(0);
+      float mx = 0.f;
+      if constexpr (NEXT) mx = row_max(sn);
+      SB();
+      pv(1);
+      SB();
+      if constexpr (NEXT) {
+        if (__builtin_expect(__any(mx > kDefer), 0)) {       // wave-uniform, rare
+          float a, c;
+          halves(mx, a, c);
+          const float delta = fmaxf(fmaxf(a, c), 0.f);
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          m_ref += delta;
+          const float nm = -m_ref;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            asm volatile("v_sub_f32 %0, %0, %1" : "+v"(sn[i]) : "v"(delta));      // -inf (a masked key) stays -inf
+            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(acc_o[0][i]) : "v"(alpha));
+            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(acc_o[1][i]) : "v"(alpha));
+            asm volatile("v_mov_b32 %0, %1" : "+v"(negm[i]) : "v"(nm));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(ls[i]) : "v"(alpha));
+        }
+      }
+      SB();
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    auto vblk = [&](int j) __attribute__((always_inline)) -> const char* { return kblock(j) + TILE; };
+    int j = 0;
+    for (; j + 3 < nb; j += 2) {                              // both blocks: a successor that is not the last, and a K block to read
+      block(sA, sB, vblk(j), kblock(j + 2), Yes{}, No{}, Yes{});
+      block(sB, sA, vblk(j + 1), kblock(j + 3), Yes{}, No{}, Yes{});
+    }
+    const int rest = nb - j;                                  // 1, 2 or 3 (wave-uniform)
+    if (rest == 1) {
+      block(sA, sB, vblk(j), pbase, No{}, No{}, No{});
+    } else if (rest == 2) {
+      block(sA, sB, vblk(j), pbase, Yes{}, Yes{}, No{});
+      block(sB, sA, vblk(j + 1), pbase, No{}, No{}, No{});
+    } else {
+      block(sA, sB, vblk(j), kblock(j + 2), Yes{}, No{}, Yes{});
+      block(sB, sA, vblk(j + 1), pbase, Yes{}, Yes{}, No{});
+      block(sA, sB, vblk(j + 2), pbase, No{}, No{}, No{});
+    }
+    float la, lc;
+    halves((ls[0] + ls[1]) + (ls[2] + ls[3]), la, lc);
+    const float inv = 1.0f / (la + lc);
+    const int qrow = (qb * 8 + wave) * 32 + qn;              // (the swaps need every lane; only the store is predicated)
+    store_rows32<T>(O + (static_cast<size_t>(b) * Tq + (qrow < Tq ? qrow : Tq - 1)) * ldo + h * HD, acc_o, inv, hh, qrow < Tq);
+  }
+  }   // query blocks
+#undef SB
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -545,8 +796,8 @@ bool mfma_attention32_supported(int dtype, const AttnArgs& a) {
   if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
   if (a.hd != HD || a.Q2 != nullptr || a.key_len != nullptr) return false;
   if (a.Tq < 128 || a.Tq % 128 || a.S < BKV || a.S % BKV) return false;
-  if (a.ldq % 8 || a.ldkv % 8 || a.ldo % 4) return false;
-  return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 8);
+  if (a.ldq % 8 || a.ldkv % 8 || a.ldo % 8) return false;      // 16-byte output stores
+  return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 16);
 }
 
 #ifdef D3PM_ABLATIONS
@@ -557,6 +808,37 @@ int read_attn32_stamps(unsigned long long* out, int n) {
   return D3PM_OK;
 }
 #endif
+
+// the cross-attention pair of a block with both K / V images resident (<= 64 text keys, <= 256 prompt keys), no key lengths
+bool mfma_attention32_cross_supported(int dtype, const AttnArgs& a) {
+  if (dtype != D3PM_F16 && dtype != D3PM_BF16) return false;
+  if (a.hd != HD || a.Q2 == nullptr || a.key_len != nullptr) return false;
+  if (a.S < 1 || a.S > BKV || a.S2 < 1 || a.S2 > 4 * BKV || a.Tq < 1) return false;
+  if (a.ldq % 8 || a.ldkv % 8 || a.ldo % 8) return false;      // 16-byte output stores
+  return aligned(a.Q, 16) && aligned(a.K, 16) && aligned(a.V, 16) && aligned(a.O, 16) && aligned(a.Q2, 16) && aligned(a.K2, 16) &&
+         aligned(a.V2, 16) && aligned(a.O2, 16);
+}
+
+int mfma_attention32_cross(int dtype, const AttnArgs& a, int n_qsplit, hipStream_t s) {
+  const int n_qblocks = (a.Tq + 255) / 256;
+  const dim3 grid(static_cast<unsigned>(n_qsplit * a.H * a.B)), block(512);
+  const size_t lds = static_cast<size_t>(1 + (a.S2 + BKV - 1) / BKV) * 2 * TILE;
+  auto go = [&](auto* tag) -> int {
+    using U = std::remove_pointer_t<decltype(tag)>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_cross_hd64<U>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 2 * TILE));
+      attr_set = true;
+    }
+    attn32_cross_hd64<U><<<grid, block, lds, s>>>(static_cast<const U*>(a.Q), static_cast<const U*>(a.K), static_cast<const U*>(a.V),
+                                                  static_cast<U*>(a.O), a.S, static_cast<const U*>(a.Q2), static_cast<const U*>(a.K2),
+                                                  static_cast<const U*>(a.V2), static_cast<U*>(a.O2), a.S2, a.ldq, a.ldkv, a.ldo, a.Tq,
+                                                  a.scale, a.H, n_qblocks, n_qsplit);
+    D3PM_LAUNCH_CHECK();
+    return D3PM_OK;
+  };
+  return dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
+}
 
 int mfma_attention32(int dtype, const AttnArgs& a, hipStream_t s) {
   const int n_qblocks = a.Tq / 128;

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 F32, F16, BF16 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_GREEDY, FLAG_FORCE_GENERIC, FLAG_SEED_IN_HBM = 1, 2, 4
 K_GEMM, K_ATTN, K_SAMPLE, K_LN, K_GEMM_LN, K_ALL = 0, 1, 2, 3, 4, 5
 
@@ -143,6 +143,9 @@ SIGNATURES = {
     "d3pm_op_attention": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.POINTER(Tuning), C.c_void_p]),
+    "d3pm_op_attention_pair": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_float, C.POINTER(Tuning), C.c_void_p]),
     "d3pm_op_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_float, C.c_void_p]),
     "d3pm_op_linear_rowpanel": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -691,6 +694,24 @@ def op_attention(q, k, v, n_heads, scale, *, family=0):
                                   B, Tq, S, n_heads, d // n_heads, float(scale), C.byref(TUNING), stream_ptr()),
           "d3pm_op_attention")
     return o
+
+
+def op_attention_pair(q1, k1, v1, q2, k2, v2, n_heads, scale):
+    """The text / prompt cross-attention pair of a block as one launch: q1, q2 [B,Tq,d]; k1 / v1 [B,S1,d], k2 / v2 [B,S2,d] (K / V
+    views of one packed [.., 2d] cache row allowed) -> (o1, o2) [B,Tq,d]."""
+    B, Tq, d = q1.shape
+    S1, S2 = k1.shape[1], k2.shape[1]
+    for t in (q1, q2, k1, v1, k2, v2):
+        assert t.stride(2) == 1
+    assert q1.stride(1) == q2.stride(1) and k1.stride(1) == v1.stride(1) == k2.stride(1) == v2.stride(1)
+    assert q1.stride(0) == Tq * q1.stride(1) and q2.stride(0) == Tq * q2.stride(1)
+    assert k1.stride(0) == S1 * k1.stride(1) and k2.stride(0) == S2 * k2.stride(1)
+    o1 = torch.empty((B, Tq, d), dtype=q1.dtype, device=q1.device)
+    o2 = torch.empty_like(o1)
+    check(lib().d3pm_op_attention_pair(dtype_code(q1.dtype), _p(q1), _p(k1), _p(v1), _p(o1), S1, _p(q2), _p(k2), _p(v2), _p(o2), S2,
+                                       q1.stride(1), k1.stride(1), d, B, Tq, n_heads, d // n_heads, float(scale), C.byref(TUNING),
+                                       stream_ptr()), "d3pm_op_attention_pair")
+    return o1, o2
 
 
 def op_layernorm(x, w, b, film=None, eps=1e-6):
