@@ -11,6 +11,8 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tts-with-diffusion-model_amd"))
 from vall_e.vall_e import _hip  # noqa: E402
 
+_hip.use_ab_library()      # arm 35 (192-query workgroups) lives in libd3pm_hip_ab.so only: __graft_entry__.build_ab()
+
 DEV = "cuda:0"
 
 
@@ -59,11 +61,18 @@ def main():
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
         fl = 4.0 * B * H * T * T * hd
         line = f"self-attention B={B} T={T}:"
-        for qg in (1, 2, 33, 32):
-            _hip.set_attn_query_groups(qg)
-            us = timeit(lambda: _hip.op_attention(q, k, v, H, scale))
+        outs = {}
+        res = {qg: [] for qg in (2, 33, 32, 35)}
+        for rep in range(3):                       # interleaved repetitions; 32 / 35 = the pipelined kernel with 128- / 192-query workgroups
+            for qg in res:
+                _hip.set_attn_query_groups(qg)
+                res[qg].append(timeit(lambda: _hip.op_attention(q, k, v, H, scale)))
+                if rep == 0:
+                    outs[qg] = _hip.op_attention(q, k, v, H, scale)
+        for qg in res:
+            us = sorted(res[qg])[1]
             line += f"  qg{qg} {us:7.1f} us {fl / us / 1e6:7.1f} TF/s |"
-        print(line, flush=True)
+        print(line + f"  192- and 128-query workgroups bit-identical: {torch.equal(outs[32], outs[35])}", flush=True)
     _hip.set_attn_query_groups(0)
 
 

@@ -700,7 +700,12 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
   {
     const long long wgs32 = static_cast<long long>(a.Tq / 128) * a.H * a.B;
     const int q = tn.attn_query_groups;
-    if ((q == 32 || q == 33 || (q == 0 && wgs32 >= 512)) && mfma_attention32_supported(dtype, a)) return mfma_attention32(dtype, a, s);
+#ifdef D3PM_ABLATIONS
+    const bool arm35 = q == 35;      // A/B library: the pipelined kernel with 192-query workgroups (d3pm_mfma_attn32.hip)
+#else
+    const bool arm35 = false;
+#endif
+    if ((q == 32 || q == 33 || arm35 || (q == 0 && wgs32 >= 512)) && mfma_attention32_supported(dtype, a)) return mfma_attention32(dtype, a, s);
   }
   const long long cross_wgs = static_cast<long long>((a.Tq + 255) / 256) * a.H * a.B;
   if ((g_attn_cross_resident >= 2 || (g_attn_cross_resident == 1 && cross_wgs >= 256)) && a.Q2 != nullptr && a.key_len == nullptr &&

@@ -289,8 +289,11 @@ __global__ __launch_bounds__(256, 2) void attn32_hd64(const T* __restrict__ Q, i
 // ABL != 0: timing-only ablations for tools/probe_attn32.hip (WRONG results): 1 no exponentials, 2 no S products, 4 no P.V
 // products, 8 no V fragment reads, 16 no K fragment reads, 32 no staging / barrier after the prologue, 64 no maximum / test,
 // 128 no packing, 256 no row sum
-template <typename T, int STAMP = 0, int ABL = 0>
-__global__ __launch_bounds__(256, 3) void attn32p_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
+// NW = waves (32-query groups) per workgroup: 4 = 128 queries, three workgroups per CU; 6 = 192 queries, two workgroups per CU --
+// the same twelve waves per CU, but every staged K / V tile serves half as many queries again (a third fewer bytes L2 -> LDS and
+// staging instructions per query; waves 4 and 5 do not stage).  A query's arithmetic does not depend on NW: bit-identical.
+template <typename T, int STAMP = 0, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void attn32p_hd64(const T* __restrict__ Q, int ldq, const T* __restrict__ Kp,
                                                        const T* __restrict__ Vp, int ldkv, T* __restrict__ O, int ldo, int Tq,
                                                        int S, float scale, int H, int n_qblocks) {
   __shared__ __attribute__((aligned(16))) char smem[3 * 2 * TILE];   // [buffer][K tile | V tile]
@@ -303,7 +306,8 @@ __global__ __launch_bounds__(256, 3) void attn32p_hd64(const T* __restrict__ Q, 
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int qb = bid % n_qblocks, h = (bid / n_qblocks) % H, b = bid / (n_qblocks * H);
-  const int q0 = (qb * 4 + wave) * 32;
+  const int q0 = (qb * NW + wave) * 32;
+  const bool stager = NW == 4 || wave < 4;               // wave-uniform: 256 threads stage a tile
   const int qn = lane & 31, hh = lane >> 5;
   const T* Kb = Kp + static_cast<size_t>(b) * S * ldkv + h * HD;
   const T* Vb = Vp + static_cast<size_t>(b) * S * ldkv + h * HD;
@@ -345,11 +349,13 @@ __global__ __launch_bounds__(256, 3) void attn32p_hd64(const T* __restrict__ Q, 
   };
 
   const int n_tiles = S / BKV;
-  Staged st = load_tile(0);
-  store_tile(smem, st);
-  if (n_tiles > 1) {
-    st = load_tile(1);
-    store_tile(smem + 2 * TILE, st);
+  if (stager) {
+    Staged st = load_tile(0);
+    store_tile(smem, st);
+    if (n_tiles > 1) {
+      st = load_tile(1);
+      store_tile(smem + 2 * TILE, st);
+    }
   }
   __syncthreads();
 
@@ -440,11 +446,13 @@ __global__ __launch_bounds__(256, 3) void attn32p_hd64(const T* __restrict__ Q, 
       else acc_o[db] = mma32<T>(vf[db], pf, acc_o[db]);
     };
     SB();
-    if constexpr (STG != 0) {      // unconditional (a branch here splits the block and hipcc sinks the vector work behind it): past the
-      // end the last tile is staged again, into a buffer that is no longer read
-      const char* gt = reinterpret_cast<const char*>((STG == 1 ? Kb : Vb) + static_cast<size_t>(stile < n_tiles ? stile : n_tiles - 1) * BKV * ldkv);
-      h0 = *reinterpret_cast<const uint4*>(gt + lo0);
-      h1 = *reinterpret_cast<const uint4*>(gt + lo1);
+    if constexpr (STG != 0) {      // unconditional in the tile index (a branch on it splits the block and hipcc sinks the vector work
+      // behind it): past the end the last tile is staged again, into a buffer that is no longer read
+      if (NW == 4 || stager) {
+        const char* gt = reinterpret_cast<const char*>((STG == 1 ? Kb : Vb) + static_cast<size_t>(stile < n_tiles ? stile : n_tiles - 1) * BKV * ldkv);
+        h0 = *reinterpret_cast<const uint4*>(gt + lo0);
+        h1 = *reinterpret_cast<const uint4*>(gt + lo1);
+      }
     }
     read_v(0, 0);
     read_v(0, 1);
@@ -478,8 +486,10 @@ __global__ __launch_bounds__(256, 3) void attn32p_hd64(const T* __restrict__ Q, 
     SB();
     pv(1, 1);
     if constexpr (STG != 0) {
-      *reinterpret_cast<uint4*>(sdst + (STG == 1 ? ko0 : TILE + vo0)) = h0;
-      *reinterpret_cast<uint4*>(sdst + (STG == 1 ? ko1 : TILE + vo1)) = h1;
+      if (NW == 4 || stager) {
+        *reinterpret_cast<uint4*>(sdst + (STG == 1 ? ko0 : TILE + vo0)) = h0;
+        *reinterpret_cast<uint4*>(sdst + (STG == 1 ? ko1 : TILE + vo1)) = h1;
+      }
     }
     SB();
     if constexpr (NEXT && !(ABL & 64)) {
@@ -870,6 +880,22 @@ int mfma_attention32(int dtype, const AttnArgs& a, hipStream_t s) {
   }
 #endif
   if (tune_of(a.tune).attn_query_groups != 33) {           // 33: the plain walk (A/B against the pipelined one)
+#ifdef D3PM_ABLATIONS
+    // A/B library only (attn_query_groups = 35): 192-query workgroups of six waves, two per CU -- a third fewer K / V bytes staged
+    // per query, bit-identical, measured SLOWER (65.8 vs 52.8 us at 32 x 768, 23.0 vs 19.4 at 32 x 384: tests/ab_attn32.py,
+    // profiles/round3_t_ab_attn32.txt): the staged bytes are not what this kernel waits for
+    if (tune_of(a.tune).attn_query_groups == 35 && a.Tq % 192 == 0) {
+      const dim3 grid6(static_cast<unsigned>(a.Tq / 192 * a.H * a.B)), block6(384);
+      if (dtype == D3PM_F16)
+        attn32p_hd64<f16, 0, 0, 6><<<grid6, block6, 0, s>>>(static_cast<const f16*>(a.Q), a.ldq, static_cast<const f16*>(a.K), static_cast<const f16*>(a.V),
+                                                            a.ldkv, static_cast<f16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, a.Tq / 192);
+      else
+        attn32p_hd64<bf16, 0, 0, 6><<<grid6, block6, 0, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), static_cast<const bf16*>(a.V),
+                                                             a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, a.Tq / 192);
+      D3PM_LAUNCH_CHECK();
+      return D3PM_OK;
+    }
+#endif
     if (dtype == D3PM_F16)
       attn32p_hd64<f16><<<grid, block, 0, s>>>(static_cast<const f16*>(a.Q), a.ldq, static_cast<const f16*>(a.K), static_cast<const f16*>(a.V),
                                                a.ldkv, static_cast<f16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks);

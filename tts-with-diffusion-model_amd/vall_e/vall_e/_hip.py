@@ -823,7 +823,7 @@ def set_gemm_variant(v: int):
 
 
 def set_attn_query_groups(v: int):
-    if v not in (0, 1, 2, 4, 32, 33):
+    if v not in (0, 1, 2, 4, 32, 33) and not (v == 35 and _is_ab):      # 35: A/B library only (192-query workgroups)
         raise D3PMError(f"attn_query_groups {v}: not a shipped schedule (include/d3pm_hip.h)")
     lib()
     TUNING.attn_query_groups = v
