@@ -13,7 +13,7 @@ import sys
 
 import re
 
-CLASSES = {"gemm": "gemm_mfma", "gemm_layernorm": "gemm_mfma_big", "gemm_mx": "gemm_mx_big", "attention": "attn_", "layernorm": "layernorm",
+CLASSES = {"gemm": "gemm_mfma", "gemm_layernorm": "gemm_mfma_big", "gemm_mx": "gemm_mx_big", "attention": "attn", "layernorm": "layernorm",
            "sample": "posterior_sample", "embed": "embed_rows"}
 
 
