@@ -594,9 +594,15 @@ int big_linear_tile(int dtype, const LinearArgs& a, int want) {
     return tiles * 5 >= slots * 4 && tiles * 100 >= rounds * slots * 85;   // >= 85 % of the slot-rounds do work
   };
   if (want >= 1 && want <= 3) return fits(want, true) ? want : 0;
-  // measured at the bench shapes (tests/ab_gemm.py, profiles/round2_*): 192 x 256 wins everywhere except under the GELU
-  // epilogue, whose VALU work only overlaps with MFMAs when a second workgroup shares the CU (192 x 128, two per CU)
-  if (gelu && !(dtype == D3PM_BF16 && gelu_table_enabled()) && fits(3, false)) return 3;   // bf16: table lookup, cheap enough for one WG per CU
+  // Under the GELU epilogue 192 x 128 tiles win clearly: its VALU work only overlaps with MFMAs when a second workgroup shares the
+  // CU (two 4-wave workgroups per CU).  For the other K = 512 projections the microbenchmark cannot tell 192 x 128 from 192 x 256
+  // (qkv 43.3 vs 44.5 us, merged q 30.5 vs 31.4: profiles/round3_v_ab_gemm_geometries.txt) but the sampler's loop can, where the
+  // operands arrive cold from the previous launch and two independent workgroups per CU hide that better than one: GEMM class
+  // 1317 -> 1241 us per iteration, 97.8 k -> 101.2 k tokens/s with 192 x 128 everywhere (interleaved arms of bench.py --tune
+  // gemm_variant=8, profiles/round3_v_ab_tune_geom.txt)
+  // -- and fc2 (K = 2048) likewise: with 192 x 128 for the K = 512 projections only the class is at 1294 us, with fc2 too at 1249
+  // (profiles/round3_w_ab_tune_geom.txt).  So: two 4-wave workgroups per CU wherever that geometry fills its rounds.
+  if (fits(3, false)) return 3;
   if (fits(2, false)) return 2;
   if (fits(3, false)) return 3;
   if (fits(1, false)) return 1;

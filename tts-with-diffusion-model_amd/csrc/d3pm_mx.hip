@@ -364,10 +364,11 @@ static int mx_geometry(const MxLinearArgs& a) {
     const long long tiles = static_cast<long long>(a.M / tm) * (a.N / tn), rounds = (tiles + slots - 1) / slots;
     return tiles * 100 >= rounds * slots * 85 || tiles >= 4 * slots;      // >= 85 % of the slot-rounds do work
   };
-  const bool gelu = a.act == ACT_GELU;
-  if (gelu && fits(192, 128, 512)) return 3;      // the VALU epilogue overlaps with the other workgroup's MFMAs
-  if (fits(192, 256, 256)) return 2;
+  // two 4-wave workgroups per CU first, as for the 16-bit big tiles (d3pm_mfma_gemm_big.hip, big_linear_tile): in the sampler's loop
+  // the operands arrive cold and a second workgroup hides that (fp8 50-step path 224.0 k -> 227.3 k tokens/s,
+  // profiles/round3_w_fp8_geom.txt); under the GELU epilogue its VALU work also overlaps with the other workgroup's MFMAs
   if (fits(192, 128, 512)) return 3;
+  if (fits(192, 256, 256)) return 2;
   if (a.M % 192 == 0 && a.N % 256 == 0) return 2;
   if (a.M % 192 == 0 && a.N % 128 == 0) return 3;
   return 0;
