@@ -1,4 +1,4 @@
-# final measurements of a round: bash tools/_final.sh <tag>   (GPU box; outputs under gpurun_out/<tag>_*)
+# final measurements of a round: bash tools/final_measure.sh <tag>   (GPU box; outputs under gpurun_out/<tag>_*)
 tag=${1:-final}
 : "${GRAFT_REPO_ROOT:=$(pwd)}"; export GRAFT_REPO_ROOT
 mkdir -p gpurun_out
