@@ -68,6 +68,7 @@ class _BlockParams(nn.Module):
 class NAR(SymmapState, nn.Module):
     n_resp_levels = 7
     n_prom_levels = 8
+    pad_rows_to_tiles = True      # _pack: round the padded grid up so that batch * t_max is a multiple of 192 (big-tile GEMMs)
 
     def __init__(self, n_tokens: int = 1024, d_model: int = 512, n_heads: int = 8, n_layers: int = 12, p_dropout: float = 0.1):
         super().__init__()
@@ -119,6 +120,14 @@ class NAR(SymmapState, nn.Module):
         resp = pad_sequence([F.pad(i32(r), (0, self.n_resp_levels + 1 - r.shape[-1])) for r in resps_list], batch_first=True)
         lens = torch.tensor(lens_host, dtype=torch.int32).to(dev, non_blocking=True)
         t_max = max(a + b_ + c for a, b_, c in lens_host) + 2
+        if self.pad_rows_to_tiles:
+            # t_max is the padded grid's row count per utterance (rows past an utterance's own length are masked padding): a few more
+            # of them make batch * t_max a multiple of 192, so the projections run as big-tile GEMMs (192 x 128) instead of
+            # one 128 x 128 tile per workgroup -- same bits (the schedules accumulate in the same order)
+            step = 192 // math.gcd(len(lens_host), 192)
+            padded = -(-t_max // step) * step
+            if padded * 100 <= t_max * 103:
+                t_max = padded
         return lens, text.contiguous(), prom.contiguous(), resp.contiguous(), t_max, lens_host
 
     @torch.no_grad()
