@@ -210,3 +210,23 @@ def test_mx_quantiser_layout_and_error_bound():
     bm = w.abs().reshape(6, 8, 32).amax(dim=-1).repeat_interleave(32, dim=1)
     assert ((deq - w).abs() <= 0.0625 * w.abs() + 2.0 ** -9 * bm).all()
     assert (codes & 0x7F).max().item() <= 0x7E
+
+
+def test_nar_grid_is_padded_to_whole_gemm_tiles_only_when_cheap():
+    """NAR._pack rounds the padded grid up so that batch * t_max is a multiple of 192 (the projections then run as big-tile
+    GEMMs), but never by more than 3 %: small batches keep their exact t_max.  Host logic only (the packer reads no device memory)."""
+    from vall_e.vall_e import NAR
+    m = NAR(1024, 64, 1, 1)                     # parameters on the CPU: the packer's grids stay there too
+
+    def t_max(batch, t, p, r):
+        lists = [torch.zeros(t, dtype=torch.int64)] * batch, [torch.zeros(p, 8, dtype=torch.int64)] * batch, [torch.zeros(r, 1, dtype=torch.int64)] * batch
+        return m._pack(*lists)[4]
+
+    assert t_max(32, 50, 225, 750) == 1032 and (32 * 1032) % 192 == 0          # 1027 -> 1032: + 0.5 %
+    assert t_max(2, 10, 20, 30) == 62                                          # 62 -> 96 would be + 55 %: untouched
+    assert t_max(3, 50, 225, 750) == 1027                                      # 1027 -> 1088 would be + 5.9 %: untouched
+    try:
+        NAR.pad_rows_to_tiles = False
+        assert t_max(32, 50, 225, 750) == 1027
+    finally:
+        NAR.pad_rows_to_tiles = True
