@@ -224,12 +224,12 @@ def test_attention_mfma_vs_generic_vs_torch(attn_qg, dtype, Tq, S):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("resident", [0, 4, 5], ids=["tile_by_tile", "resident16", "resident32"])
+@pytest.mark.parametrize("resident", [0, 4, 5, -4], ids=["tile_by_tile", "resident16", "resident32", "key_split"])
 @pytest.mark.parametrize("Tq,S1,S2", [(768, 50, 225), (448, 50, 200), (384, 64, 256), (300, 1, 33), (768, 33, 97), (256, 32, 1), (512, 17, 160)])
 def test_attention_pair_vs_torch(built_lib, dtype, resident, Tq, S1, S2):
     """The text / prompt cross-attention pair of a block (d3pm_op_attention_pair) on every schedule -- tile by tile, both K / V
-    images resident on the 16 x 16 x 32 instruction, resident on the 32 x 32 x 16 instruction with the software-pipelined 32-key
-    block (key counts that end inside a block are masked through the product's C operand; blocks past the last key are not
+    images resident on the 16 x 16 x 32 instruction, the opt-in key-split kernel, resident on the 32 x 32 x 16 instruction with the
+    software-pipelined 32-key block (key counts that end inside a block are masked through the product's C operand; blocks past the last key are not
     walked) -- against torch fp32 on the same 16-bit inputs, K / V as views of packed cache rows."""
     from vall_e.vall_e import _hip
     B, H, hd = 3, 8, 64
@@ -244,10 +244,15 @@ def test_attention_pair_vs_torch(built_lib, dtype, resident, Tq, S1, S2):
     ref2 = torch_attention(q2, kv2[..., :d], kv2[..., d:], H, scale)
     tol = 4e-3 if dtype == torch.float16 else 3e-2
     try:
-        _hip.set_attn_cross_resident(resident)
+        if resident == -4:                       # the opt-in key-split kernel (attn_query_groups = 4), pair = the two halves of its grid
+            _hip.set_attn_cross_resident(0)
+            _hip.set_attn_query_groups(4)
+        else:
+            _hip.set_attn_cross_resident(resident)
         o1, o2 = _hip.op_attention_pair(q1, kv1[..., :d], kv1[..., d:], q2, kv2[..., :d], kv2[..., d:], H, scale)
     finally:
         _hip.set_attn_cross_resident(1)
+        _hip.set_attn_query_groups(0)
     for name, o, ref in (("text", o1, ref1), ("prompt", o2, ref2)):
         assert torch.isfinite(o).all()
         err = (o.float() - ref).abs().max().item()
