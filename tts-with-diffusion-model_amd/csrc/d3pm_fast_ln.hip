@@ -20,7 +20,15 @@ __global__ __launch_bounds__(256) void layernorm_vec(const T* __restrict__ x, T*
                                                      int canvas, int n_classes, T* __restrict__ xout) {
   constexpr int d = CH * 512;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous range of rows -- the ranges
+  // the GEMM tiles that wrote these rows and the ones that read the result are dealt in (LayerNorm class 74 -> 70 us per iteration
+  // in the loop: part of its input is still in the XCD's own L2; profiles/round3_l2_ab_ln_xcd.txt)
+  int bidx;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bidx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int row = bidx * 4 + wave;
   if (row >= M) return;
   const T* xr = x + static_cast<size_t>(row) * d;
   bool live = true;

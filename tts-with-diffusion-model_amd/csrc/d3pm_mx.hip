@@ -64,7 +64,12 @@ __global__ __launch_bounds__(256) void layernorm_mx_rows(const T* __restrict__ x
                                                          uint8_t* __restrict__ sx_2, int M, float eps) {
   constexpr int d = 512;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
+  int bidx;      // XCD-aware order, as layernorm_vec: each XCD takes a contiguous range of rows
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bidx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int row = bidx * 4 + wave;
   if (row >= M) return;
   const Vec8<T> raw = *reinterpret_cast<const Vec8<T>*>(x + static_cast<size_t>(row) * d + lane * 8);
   float v[8], s = 0.f;
