@@ -106,7 +106,9 @@ enum {
  *                      next block's norm1; 8 = at one or two utterances (batch * canvas <= 2048 rows, where no row panel applies)
  *                      both cross-attention out-projections as ONE launch of the latency GEMM: two products through one resident
  *                      weight panel, the first result kept in registers (same bits as the two launches it replaces).
- *                      Default 11 (fc2 measured slower fused).
+ *                      Default 10: in the sampler's loop the fc2 form (4) is slower fused, and since the plain projections run as two
+ *                      4-wave workgroups per CU the self-attention form (1) is too (102.6 k vs 103.7 k tokens/s, round 3); the dual
+ *                      cross-attention form (2) and the latency form (8) pay.
  *   workspace_alias    1 (default) = the packed qkv rows, the MLP hidden rows and the logits of an iteration share one
  *                      workspace region (never live together); 0 = separate regions.  d3pm_workspace_bytes and the step /
  *                      loop calls must see the same value.

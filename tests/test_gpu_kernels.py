@@ -530,7 +530,7 @@ def test_sample_loop_is_the_same_with_and_without_row_panel_launches(built_lib):
             _hip.set_row_panel(maskbits)
             outs.append(m.generate_audio(texts, proms, steps=3, seed=4).clone())
     finally:
-        _hip.set_row_panel(11)
+        _hip.set_row_panel(10)
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
 
@@ -560,7 +560,7 @@ def test_dual_out_projection_of_the_latency_regime_is_bit_identical(built_lib, d
             ids = m.generate_audio(texts, proms, steps=3, seed=4)
             outs.append((lg.clone(), hid.clone(), ids.clone()))
     finally:
-        _hip.set_row_panel(11)
+        _hip.set_row_panel(10)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
 

@@ -65,7 +65,7 @@ def test_product_library_holds_no_experiments_and_no_tuning_state(built_lib):
     built_lib.d3pm_tuning_default(C.byref(a))
     built_lib.d3pm_tuning_default(C.byref(b))
     b.gemm_variant = 5
-    assert (a.gemm_variant, a.gemm_persist_slots, a.row_panel, a.workspace_alias, a.attn_cross_resident) == (0, 1024, 11, 1, 1)
+    assert (a.gemm_variant, a.gemm_persist_slots, a.row_panel, a.workspace_alias, a.attn_cross_resident) == (0, 1024, 10, 1, 1)
     # workspace_alias is read from the shape's tuning, not from a global
     from vall_e.vall_e import synth
     cfg = synth.D3PMConfig.libritts()

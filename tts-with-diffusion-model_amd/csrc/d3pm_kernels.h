@@ -14,7 +14,7 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SILU = 3 };
 // The library has no mutable global state: the defaults are a constant.
 inline const d3pm_tuning& tune_of(const d3pm_tuning* t) {
   static const d3pm_tuning kDefault = {/*gemm_variant*/ 0, /*gemm_persist_slots*/ 1024, /*lat_tile*/ 0, /*attn_query_groups*/ 0,
-                                       /*attn_pair_sequential*/ 1, /*attn_cross_resident*/ 1, /*row_panel*/ 11, /*workspace_alias*/ 1,
+                                       /*attn_pair_sequential*/ 1, /*attn_cross_resident*/ 1, /*row_panel*/ 10, /*workspace_alias*/ 1,
                                        /*prof*/ nullptr};
   return t ? *t : kDefault;
 }
