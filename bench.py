@@ -396,8 +396,8 @@ def main():
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic("gemm") if args.config == "libritts" and batch == 32 else (None, "PMC passes cover the headline workload only")
         result["roofline"] = {"bound": "mfma", "kernel": "gemm_mfma_* (the plain DiT projection / MLP / final GEMM launches inside the diffusion "
-                              "loop: the largest class; the out-projections fused with the next LayerNorms are the gemm_layernorm row "
-                              "of kernel_classes)",
+                              "loop, incl. the self-attention out-projection: the largest class; the dual cross-attention out-projection fused "
+                              "with norm3 / FiLM is the gemm_layernorm row of kernel_classes)",
                               "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[key], "unit": "TFLOP/s",
                               "frac": achieved / MFMA_PEAK_TFLOPS[key], "traffic": traffic,
                               "traffic_unit": "bytes/launch (L2 fabric-side, rocprofv3 PMC)", "traffic_source": traffic_src,
