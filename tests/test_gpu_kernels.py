@@ -320,6 +320,22 @@ def test_layernorm_and_film(built_lib, dtype):
         assert (yf - reff).abs().max().item() < tol * 2 * max(1.0, reff.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 5, 33, 450, 1027, 4100])
+def test_layernorm_row_counts_that_do_not_fill_the_xcd_ranges(built_lib, dtype, M):
+    """layernorm_vec deals its 4-row workgroups to the 8 XCDs in contiguous ranges (blockIdx -> row remap): every row count --
+    fewer workgroups than XCDs, a remainder of 1 .. 7 workgroups, a ragged last workgroup -- must still write every row once."""
+    from vall_e.vall_e import _hip
+    g = torch.Generator(device="cpu").manual_seed(M)
+    d = 512
+    x = torch.randn(M, d, generator=g).to(dtype).to(DEV)
+    w = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype).to(DEV)
+    b = (0.1 * torch.randn(d, generator=g)).to(dtype).to(DEV)
+    ref = torch.nn.functional.layer_norm(x.float(), (d,), w.float(), b.float(), 1e-6)
+    y = _hip.op_layernorm(x, w, b)
+    assert (y.float() - ref).abs().max().item() < 16 * _eps(dtype) * max(1.0, ref.abs().max().item())
+
+
 # ---- fp8 (OCP e4m3) fast path, BASELINE.json configs[4]: no reference counterpart, pinned to torch on the SAME codes ----
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_quantize_mx_is_the_block_rule(built_lib, dtype):
