@@ -3,6 +3,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With --gpus N > 1 and no torchrun environment (no WORLD_SIZE) the script starts the N ranks itself: a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` of this same command line, launched
+before this process makes any GPU call; rank 0's JSON line and the child's exit code pass through.
+
 One "step" = one full reverse process (condition encoders + 99 denoise/sample iterations) over this
 rank's batch of utterances, inputs resident in HBM.  Workload at every N: BASELINE.json configs[1]
 ("LibriTTS"): d=512, 8 heads, 6 blocks, 750 live frames on a 768 canvas,
@@ -51,6 +55,9 @@ def parse():
                     "(include/d3pm_hip.h), e.g. row_panel=0; the JSON line records them and is not the headline configuration")
     ap.add_argument("--cpu-only", action="store_true",
                     help="time only the CPU port (no GPU needed) and print its JSON: the container calibration under profiles/")
+    ap.add_argument("--stand-in", action="store_true",
+                    help="REHEARSAL ONLY (no GPU needed): the launcher / sharding / all-gather / timing path of this script around a "
+                         "deterministic CPU stand-in for the sampler, with --backend gloo; the JSON line is marked invalid_for_headline")
     ap.add_argument("--profile-iters", type=int, default=0,
                     help="PROFILING ONLY: run this many diffusion iterations instead of all 99 (the JSON line is then "
                          "marked invalid_for_headline)")
@@ -289,12 +296,117 @@ def cpu_baseline(cfg, sd32, texts, proms, n_iters):
     return out
 
 
+def reduce_over_ranks(elapsed: float, world: int, dev):
+    """(max over ranks of the timed region, number of ranks that took part): the second is an all-reduce of ones, so a line
+    that says n_gpus = N was produced by N live ranks."""
+    if world == 1:
+        return elapsed, 1
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    ones = torch.ones(1, device=dev, dtype=torch.int32)
+    torch.distributed.all_reduce(ones, op=torch.distributed.ReduceOp.SUM)
+    return t.item(), int(ones.item())
+
+
+def stand_in_main(args, rank, world):
+    """The N-rank path of this script without a GPU: same sharding (dp.generate_audio_dp), same barrier / max-over-ranks timing, same
+    JSON contract, a CPU stand-in where the HIP sampler would run.  A rehearsal, never a measurement."""
+    import torch.distributed as dist
+    from vall_e.vall_e import dp, synth
+    if args.backend != "gloo":
+        raise SystemExit("--stand-in runs on the CPU: use --backend gloo")
+    if world > 1:
+        dist.init_process_group("gloo")
+    cfg = {"libritts": synth.D3PMConfig.libritts, "native": synth.D3PMConfig.native,
+           "vctk": synth.D3PMConfig.vctk_long_prompt}[args.config]()
+    batch = args.batch or (32 if args.config != "native" else 1)
+    model = StandInModel(cfg)
+    texts, proms = synth.make_inputs(cfg, batch * world, 1)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        dp.generate_audio_dp(model, texts, proms, seed=123 + i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = dp.generate_audio_dp(model, texts, proms, seed=123 + args.warmup + i)
+    fence()
+    elapsed, ranks_seen = reduce_over_ranks(time.perf_counter() - t0, world, torch.device("cpu"))
+    assert out.shape == (batch * world, cfg.canvas)
+    single = StandInModel(cfg).generate_audio(texts, proms, seed=123 + args.warmup + args.steps - 1).reshape(batch * world, -1)
+    assert torch.equal(out, single.long()), "gathered grid differs from the one-rank grid"
+    if rank == 0:
+        print(json.dumps({"metric": "EnCodec codec-tokens/sec (whole node), 100-step D3PM", "value": batch * world * cfg.n_frames * args.steps / elapsed,
+                          "unit": "codec_tokens/s", "n_gpus": world, "n_ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "int64", "data": "synthetic",
+                          "config": {"workload": f"{args.config}: CPU stand-in for the sampler", "utterances_per_gpu": batch,
+                                     "global_batch": batch * world, "parallelism": f"dp{world}"},
+                          "stand_in": True, "invalid_for_headline": "rehearsal of the launcher / sharding / gather path on the CPU: no kernel ran"}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def cfg_name(cfg):
     return f"d={cfg.d_model} H={cfg.n_heads} L={cfg.n_layers} T={cfg.n_frames}/{cfg.canvas} S_prompt={cfg.s_prompt} steps={cfg.timesteps - 1}"
 
 
+def launch_ranks(args) -> int:
+    """--gpus N > 1 outside torchrun: this process becomes the launcher.  It makes no GPU call (torch.cuda.device_count() only
+    counts devices), starts `python -m torch.distributed.run` with one rank per GPU as a CHILD process (never an exec: a
+    process that has touched the GPU must not be replaced) and returns the child's exit code; the ranks inherit stdout, so
+    rank 0's JSON line is this command's JSON line."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.stand_in:
+        have = torch.cuda.device_count()
+        if have < n and args.backend == "nccl":
+            print(f"[bench] --gpus {n} but only {have} GPU(s) are visible: refusing to start (RCCL needs one device per rank; "
+                  "--backend gloo rehearses the path with ranks sharing a device)", file=sys.stderr, flush=True)
+            return 2
+        if have < 1:
+            print("[bench] no GPU visible", file=sys.stderr, flush=True)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+class StandInModel:
+    """--stand-in: what dp.generate_audio_dp needs from a model, on the CPU.  The ids of an utterance are a function of
+    (seed, GLOBAL utterance index) only, like the Philox rows of the real sampler, so the gathered grid is the same for
+    every rank count."""
+
+    def __init__(self, cfg):
+        self.cfg, self.device = cfg, torch.device("cpu")
+
+    def generate_audio(self, text_list, proms_list, *, seed, utt0=0, **_):
+        rows = []
+        for b in range(len(text_list)):
+            g = torch.Generator().manual_seed(int(seed) * 100003 + utt0 + b)
+            rows.append(torch.randint(0, self.cfg.n_classes, (self.cfg.canvas,), generator=g))
+        return torch.stack(rows) if len(rows) > 1 else rows[0]
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.cpu_only:
+        sys.exit(launch_ranks(args))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     if args.cpu_only:
         from vall_e.vall_e import synth
         cfg = {"libritts": synth.D3PMConfig.libritts, "native": synth.D3PMConfig.native,
@@ -308,6 +420,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.stand_in:
+        return stand_in_main(args, rank, world)
     local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
@@ -367,17 +481,14 @@ def main():
                                                                   ("gemm_layernorm", _hip.K_GEMM_LN))}
     launches, gemm_ms, gemm_flops, gemm_bytes = per_class["gemm"]
     _hip.prof_disable()
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = tmax.item()
+    elapsed, ranks_seen = reduce_over_ranks(elapsed, world, dev if args.backend == "nccl" else torch.device("cpu"))
     assert out.shape == (batch * world, cfg.canvas)
 
     tokens = batch * world * cfg.n_frames * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     result = {
         "metric": "EnCodec codec-tokens/sec (whole node), 100-step D3PM",
-        "value": tokens / elapsed, "unit": "codec_tokens/s", "n_gpus": world, "steps": args.steps,
+        "value": tokens / elapsed, "unit": "codec_tokens/s", "n_gpus": world, "n_ranks_seen": ranks_seen, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.config}: d={cfg.d_model} H={cfg.n_heads} L={cfg.n_layers} "

@@ -146,3 +146,39 @@ def test_gradient_all_reduce_world2():
             continue
         want = ((1 * (i + 1)) + (0 if i == 4 else 2 * (i + 1))) / 2.0
         assert all(abs(v - want) < 1e-6 for v in a), (i, a[0], want)
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start two ranks itself (a child torch.distributed.run,
+    launched before the parent touches a GPU) and forward rank 0's JSON line: n_gpus == n_ranks_seen == 2.  The sampler is the
+    CPU stand-in of bench.py (--stand-in), everything around it -- launcher, env rendezvous on 127.0.0.1, sharding by rank,
+    all-gather, barrier + max-over-ranks timing, the JSON contract -- is the code the 8-GPU run goes through."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "native",
+                          "--cpu-steps", "0", "--stand-in", "--batch", "3", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["config"]["global_batch"] == 6
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak" and out["stand_in"] is True
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
+        assert key in out
+
+
+def test_bench_launcher_refuses_more_ranks_than_gpus():
+    """--gpus N on a box with fewer than N GPUs must fail non-zero instead of printing an n_gpus = 1 line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.device_count() >= 64:
+        pytest.skip("more GPUs than the test asks for")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode != 0 and not any(ln.startswith("{") for ln in res.stdout.splitlines())
