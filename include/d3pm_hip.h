@@ -30,6 +30,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what this header declares is exported */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* 2: + d3pm_ce_loss_rows, the fp8 entry points (d3pm_*_fp8), D3PM_FLAG_SEED_IN_HBM, tuning knobs 2..3, GEMM variant 5
  *    (additions only) */
@@ -43,7 +47,10 @@ extern "C" {
  *    they live in libd3pm_hip_ab.so, include/d3pm_hip_ab.h. */
 /* 5: + d3pm_op_attention_pair; new VALUES of existing tuning fields (row_panel bit 3, attn_query_groups 4, attn_cross_resident
  *    4 / 5); layouts unchanged */
-#define D3PM_ABI_VERSION 5
+/* 6: LayerNorm folded into the projections (d3pm_fold_block, d3pm_weights.fold, d3pm_fold_bytes / d3pm_fold_build,
+ *    d3pm_op_linear_fold / d3pm_op_linear_stats / d3pm_op_row_stats); d3pm_tuning gained regime_batch and ln_fold (layout change);
+ *    d3pm_workspace_bytes grew by the row-moment buffer and the fp8 path's scale slot */
+#define D3PM_ABI_VERSION 6
 
 enum { D3PM_F32 = 0, D3PM_F16 = 1, D3PM_BF16 = 2 };
 
@@ -64,9 +71,12 @@ enum {
                                   new seed (measured: no faster than eager launches, 66.6 vs 66.3 ms per utterance) */
 };
 
-/* Schedule choices.  Every value of every field gives bit-identical results: the fields select between shipped schedules
- * only.  A NULL `tuning` pointer anywhere means d3pm_tuning_default().  The struct is read during the call and never
- * retained; two threads may use different tunings at the same time.
+/* Schedule choices.  A NULL `tuning` pointer anywhere means d3pm_tuning_default().  The struct is read during the call and never
+ * retained; two threads may use different tunings at the same time.  The GEMM / workspace / row-panel fields select between
+ * schedules that give bit-identical results.  Three choices change the ORDER of a floating-point accumulation, i.e. results that
+ * agree to rounding noise, not bit for bit: the attention instruction shape (attn_query_groups 32 / 33, attn_cross_resident 4 / 5,
+ * and -- in auto mode -- the batch regime, see regime_batch) and ln_fold.  Within one setting of those a result never depends on
+ * the batch an utterance rides in, nor on how a batch is split over ranks or streams.
  *   gemm_variant       0 = auto (default): big-tile persistent schedule (192 x 256 or 96 x 512 tiles, eight waves, one workgroup
  *                          per CU) when the shape divides into >= 200 such tiles that fill whole rounds of the 256 CUs, else the
  *                          latency schedule (64 x 64 tiles, whole-K operand panels in flight) for M <= 1536 rows, the 128 x 128
@@ -112,12 +122,23 @@ enum {
  *   workspace_alias    1 (default) = the packed qkv rows, the MLP hidden rows and the logits of an iteration share one
  *                      workspace region (never live together); 0 = separate regions.  d3pm_workspace_bytes and the step /
  *                      loop calls must see the same value.
+ *   regime_batch       the batch size the AUTOMATIC attention choices (attn_query_groups = 0, attn_cross_resident = 1) are made
+ *                      for: 0 (default) = the batch of the call itself; > 0 = as if the call carried that many utterances.  The two
+ *                      instruction shapes accumulate in different orders, so a caller that splits one logical batch over ranks
+ *                      or streams (vall_e/vall_e/dp.py, AR.generate_audio(streams=)) passes the GLOBAL batch here and every shard
+ *                      then takes the kernels -- and produces the bits -- of the unsplit batch.
+ *   ln_fold            1 (default) = when d3pm_weights.fold is given, the LayerNorm-fed projections (norm1 -> QKV, norm2 | norm22 ->
+ *                      cross-attention queries, norm3 + FiLM -> fc1) read the raw residual stream and apply the LayerNorm in their
+ *                      epilogue from row moments the producing projection left behind (d3pm_fold_block): no LayerNorm launch and
+ *                      no row-panel launch in a block; 0 = the stand-alone / row-panel LayerNorm launches (the eager rounding
+ *                      points).  Ignored (= 0) for fp32 models, D3PM_FLAG_FORCE_GENERIC and the fp8 entry points.
  *   prof               optional timing hooks (d3pm_prof_create below), NULL = none. */
 struct d3pm_prof;
 typedef struct d3pm_tuning {
   int32_t gemm_variant, gemm_persist_slots, lat_tile;
   int32_t attn_query_groups, attn_pair_sequential, attn_cross_resident;
   int32_t row_panel, workspace_alias;
+  int32_t regime_batch, ln_fold;
   struct d3pm_prof *prof;
 } d3pm_tuning;
 void d3pm_tuning_default(d3pm_tuning *t);
@@ -160,11 +181,23 @@ typedef struct d3pm_block_weights {
   const void *tfc_w, *tfc_b;              /* [2d][d], [2d]     timestep_fc (:124)         */
 } d3pm_block_weights;
 
+/* A block's LayerNorms folded into the projections they feed (ar_discrete.py:131-132, 136-142, 145-159), built by
+ * d3pm_fold_build from d3pm_block_weights + the FiLM table; device pointers into the caller's `storage`.  For a projection
+ * y = LN(x) W^T + b:  w = rn(W o gamma) in the model dtype,  s[n] = sum_k w[n][k] and b[n] = sum_k W[n][k] beta[k] + b[n] in fp32, so
+ * that y = rstd_r (x_r . w^T - mean_r s) + b.  fc1 carries FiLM (gamma_k rn(1 + scale_t[k]), beta_k rn(1 + scale_t[k]) + shift_t[k]):
+ * one set per timestep. */
+typedef struct d3pm_fold_block {
+  const void *qkv_w;  const float *qkv_s, *qkv_b;     /* [3d][d]; [3d]                 norm1 -> attn in-projection                 */
+  const void *q2_w;   const float *q2_s, *q2_b;       /* [2d][d]; [2d]                 norm2 -> q rows | norm22 -> the same q rows  */
+  const void *fc1_w;  const float *fc1_s, *fc1_b;     /* [timesteps+1][4d][d]; [timesteps+1][4d]   norm3 + FiLM(t) -> mlp.fc1       */
+} d3pm_fold_block;
+
 typedef struct d3pm_weights {
   const void *resps_emb;                  /* [n_classes][d]  (:212); n_q > 1: [n_q][n_classes][d] */
   const void *time_emb;                   /* [timesteps+1][d] (:213)                      */
   const void *final_w, *final_b;          /* [n_classes][d], [n_classes] (:240); n_q > 1: [n_q * n_classes][d], [n_q * n_classes] */
   const d3pm_block_weights *blocks;       /* HOST array of n_layers entries               */
+  const d3pm_fold_block *fold;            /* HOST array of n_layers entries (d3pm_fold_build), or NULL: stand-alone LayerNorms */
 } d3pm_weights;
 
 /* Block-scaled fp8 ("MX": OCP e4m3 codes + one e8m0 power-of-two scale per 32 elements along K) copies of a block's
@@ -207,6 +240,13 @@ size_t d3pm_workspace_bytes(const d3pm_shape *shape, int batch);
  * the FiLM scale/shift depends on weights and t only, so it is tabulated once per weight set. */
 int d3pm_film_table(const d3pm_shape *shape, const d3pm_weights *w, void *film /*device*/,
                     void *stream);
+
+/* LayerNorm folded into the projections: bytes of device storage for the tables of `shape` (0 when the shape does not qualify:
+ * 16-bit dtype and d_model a multiple of 256), and the build -- `film` is the table d3pm_film_table wrote; blocks_out is a HOST
+ * array of n_layers entries that receives pointers into `storage` (pass it as d3pm_weights.fold).  Once per weight set. */
+size_t d3pm_fold_bytes(const d3pm_shape *shape);
+int d3pm_fold_build(const d3pm_shape *shape, const d3pm_weights *w, const void *film /*device*/, void *storage /*device*/,
+                    size_t storage_bytes, d3pm_fold_block *blocks_out /*host*/, void *stream);
 
 /* K/V projections of the step-invariant conditions with cross_attn's k/v rows
  * (the `k`/`v` halves of F.multi_head_attention_forward's in-projection for the calls at
@@ -391,6 +431,22 @@ int d3pm_op_layernorm_mx(int dtype, const void *X, void *Y8, void *SX, const voi
 int d3pm_op_linear_mx(int out_dtype, const void *X8, int ldx, const void *SX, const void *W8, const void *SW, const void *bias,
                       void *Y, int ldy, const void *R1, int ldr, const uint8_t *row_mask, int mask_period, void *Y8, void *SY,
                       int M, int N, int K, int act, const d3pm_tuning *tuning, void *stream);
+/* The folded-LayerNorm pieces as single ops (MFMA family, 16-bit; d3pm_fold_block above):
+ *   row_stats     stats[M][d / 32][2] = per row and 32-column part (sum x, sum x^2), fp32 -- what a producing projection leaves behind;
+ *   linear_stats  d3pm_op_linear with a residual (R1 [+ R2] [+ row mask]) that also writes the moments of the rows it stores (N = d);
+ *   linear_fold   Y = act(rstd_r (X_r . Wf^T - mean_r fold_s) + fold_b) with the moments of X's rows from `stats_in` [M][K / 32][2]
+ *                 (X = the raw rows, Wf / fold_s / fold_b as d3pm_fold_build makes them); act 0 / 1 (GELU). */
+int d3pm_op_row_stats(int dtype, const void *X, int ldx, int M, int d, float *stats, void *stream);
+int d3pm_op_linear_stats(int dtype, const void *X, int ldx, const void *W, const void *bias, void *Y, int ldy, const void *R1,
+                         const void *R2, int ldr, const uint8_t *row_mask, int mask_period, int M, int N, int K, float *stats_out,
+                         const d3pm_tuning *tuning, void *stream);
+int d3pm_op_linear_fold(int dtype, const void *X, int ldx, const void *Wf, const float *fold_s, const float *fold_b,
+                        const float *stats_in, float eps, void *Y, int ldy, int M, int N, int K, int act, const d3pm_tuning *tuning,
+                        void *stream);
+/* One projection's tables as d3pm_fold_build makes them (tests): W [N][K], bias [N] or NULL, gamma / beta [K], film NULL or
+ * (scale [K] | shift [K]) -> Wf [N][K], fold_s / fold_b [N]. */
+int d3pm_op_fold_weights(int dtype, const void *W, const void *bias, const void *gamma, const void *beta, const void *film, int N, int K,
+                         void *Wf, float *fold_s, float *fold_b, void *stream);
 int d3pm_op_attention(int dtype, int family, const void *Q, int ldq, const void *K, const void *V, int ldkv,
                       void *O, int ldo, int B, int Tq, int S, int H, int hd, float scale, const d3pm_tuning *tuning,
                       void *stream);
@@ -473,6 +529,9 @@ int d3pm_op_embed_f32(const int32_t *tok, const uint8_t *mask, int period, const
 int d3pm_op_embed_bwd_f32(const int32_t *tok, const uint8_t *mask, int period, const float *dY, float *dTable, int rows, int d,
                           int n_classes, int padding_idx, void *stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what this header declares is exported */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* D3PM_AB_GEMM_BIG_MODE  schedule of the big-tile GEMM: 1 (shipped) / 0 = hand-placed / compiler-placed fragment reads, 9 = the
  *                        output stores of a tile issued inside the next tile's k-steps, 513 = non-temporal output stores,
@@ -66,6 +70,9 @@ int d3pm_debug_gemm_clock(unsigned long long *clocks_and_ticks);
  * 4 P.V issued, 5 global loads returned, 6 LDS stores issued, 7 barrier passed. */
 int d3pm_debug_attn32_stamps(unsigned long long *out, int n);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

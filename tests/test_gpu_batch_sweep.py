@@ -28,3 +28,25 @@ def test_utterance_zero_is_the_same_in_every_batch_size(built_lib):
         assert torch.equal(out[0], ref11), f"batch {b}: utterance 0 differs in {(out[0] != ref11).sum().item()} frames"
     agree = (ref11 == ref).float().mean().item()
     assert agree > 0.99, f"across the self-attention regimes only {agree:.4f} of the ids of utterance 0 agree"
+    # told the global batch (d3pm_tuning.regime_batch), one utterance alone takes the big-batch kernels: the boundary disappears
+    alone = m.generate_audio(texts[:1], proms[:1], steps=5, seed=11, global_batch=32).reshape(-1)
+    assert torch.equal(alone, ref11)
+
+
+def test_a_shard_reproduces_the_unsplit_batch(built_lib):
+    """vall_e/vall_e/dp.py shards 32 utterances over N ranks and claims the gathered ids do not depend on N.  Utterances 8..11 --
+    what rank 2 of 8 generates -- alone (utt0 = 8, global_batch = 32) against the same utterances inside the 32-utterance batch:
+    equal ids, full 99-iteration loop, both dtypes the bench and the reference run in."""
+    from vall_e.vall_e import AR, synth
+    cfg = synth.D3PMConfig.libritts()
+    texts, proms = synth.make_inputs(cfg, 32, 1)
+    for dtype in (torch.bfloat16, torch.float16):
+        m = AR.from_config(cfg)
+        m.load_state_dict(synth.make_state_dict(cfg, 0))
+        m = m.to(dtype).to("cuda:0")
+        whole = m.generate_audio(texts, proms, seed=5)
+        shard = m.generate_audio(texts[8:12], proms[8:12], seed=5, utt0=8, global_batch=32)
+        assert torch.equal(shard, whole[8:12]), f"{dtype}: {(shard != whole[8:12]).sum().item()} ids of the shard differ from the unsplit batch"
+        # stream chunks split the batch the same way and must not change it either
+        chunked = m.generate_audio(texts, proms, seed=5, streams=4)
+        assert torch.equal(chunked, whole), f"{dtype}: stream chunking changes {(chunked != whole).sum().item()} ids"

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in declared:
         assert hasattr(built_lib, name), name
     from vall_e.vall_e import _hip as _h
-    assert built_lib.d3pm_abi_version() == _h.ABI_VERSION == 5
+    assert built_lib.d3pm_abi_version() == _h.ABI_VERSION == 6
 
 
 def test_product_library_holds_no_experiments_and_no_tuning_state(built_lib):

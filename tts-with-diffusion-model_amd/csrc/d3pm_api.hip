@@ -147,6 +147,8 @@ static int run_layernorm(const Ctx& cx, int dtype, const LayerNormArgs& a, uint3
 // ---- workspace carve-up ----------------------------------------------------------------------
 struct Workspace {
   char *x, *h, *h2, *qkv, *att, *att2, *mlp, *logits;
+  float* stats;       // [n][d / 32][2] row moments of the residual stream (LayerNorm folded into the projections, d3pm_mfma_tile.h)
+  uint8_t* mxs;       // fp8 fast path: block scales [2n][d / 32] of the LayerNorm rows (a slot of their own: nothing else ever lives here)
   size_t total;
 };
 static size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
@@ -180,6 +182,8 @@ static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
     w.mlp = take(n * 4 * d * es);
     w.logits = take(n * levels(sh) * logits_ld(sh) * es);
   }
+  w.stats = reinterpret_cast<float*>(take(n * ((d + 31) / 32) * 2 * sizeof(float)));
+  w.mxs = reinterpret_cast<uint8_t*>(take(2 * n * ((d + 31) / 32)));
   w.total = off;
   return w;
 }
@@ -204,6 +208,81 @@ static int check_shape(const d3pm_shape* sh, int batch) {
 static const char* at(const void* p, size_t elems, size_t es) { return static_cast<const char*>(p) + elems * es; }
 static char* at(void* p, size_t elems, size_t es) { return static_cast<char*>(p) + elems * es; }
 
+// The block sequence with the LayerNorms folded into the projections (ar_discrete.py:126-161; d3pm_mfma_tile.h EPI_LNF / EPI_STATS):
+//   embed (+ moments) -> n_layers x { QKV <- x [norm1 folded], self-attention, out-projection + x (+ moments),
+//   merged query projection <- x [norm2 | norm22 folded, N = 2d], paired cross-attention, both out-projections + x (+ moments),
+//   fc1 + GELU <- x [norm3 + FiLM(t) folded], fc2 + x, frame mask (+ moments) }: ten launches per block, none of them a LayerNorm.
+static int denoiser_blocks_folded(const d3pm_shape& sh, const d3pm_weights& w, int batch, const int32_t* x_t, const uint8_t* frame_mask,
+                                  int t, const void* kv_text, const void* kv_prompt, const Workspace& ws, int layers, hipStream_t s) {
+  const int dt = sh.dtype, d = sh.d_model, H = sh.n_heads, hd = d / H, T = sh.canvas, n = batch * T;
+  const Ctx cx(sh.tuning);
+  const size_t es = dtype_size(dt);
+  const float scale = static_cast<float>(std::sqrt(1.0 / static_cast<double>(hd)));
+  EmbedArgs e;
+  e.tokens = x_t; e.frame_mask = frame_mask; e.canvas = T; e.table = w.resps_emb; e.Y = ws.x;
+  e.M = n; e.d = d; e.n_classes = sh.n_classes; e.n_q = levels(sh);
+  {
+    ProfScope p(cx, D3PM_K_LN, s, 0.0, es * static_cast<double>(n) * d * 2.0);
+    D3PM_TRY(embed_tokens_stats(dt, e, ws.stats, s));
+  }
+  auto folded = [&](const void* Wf, const float* fs, const float* fb, void* Y, int N, int act) -> int {
+    LinearArgs g;
+    g.X = ws.x; g.ldx = d; g.W = Wf; g.Y = Y; g.ldy = N; g.M = n; g.N = N; g.K = d; g.act = act;
+    g.fold_s = fs; g.fold_b = fb; g.stats_in = ws.stats; g.fold_eps = 1e-6f;
+    D3PM_REQUIRE(mfma_linear_supported(dt, g), D3PM_E_SHAPE, "folded LayerNorm projection %d x %d x %d not supported", n, N, d);
+    return run_linear(cx, dt, g, 0, s);
+  };
+  for (int l = 0; l < layers; ++l) {
+    const d3pm_block_weights& b = w.blocks[l];
+    const d3pm_fold_block& f = w.fold[l];
+    // ---- self-attention ----
+    D3PM_TRY(folded(f.qkv_w, f.qkv_s, f.qkv_b, ws.qkv, 3 * d, ACT_NONE));
+    AttnArgs a;
+    a.Q = ws.qkv; a.ldq = 3 * d; a.K = at(ws.qkv, d, es); a.V = at(ws.qkv, 2 * d, es); a.ldkv = 3 * d;
+    a.O = ws.att; a.ldo = d; a.B = batch; a.Tq = T; a.S = T; a.H = H; a.hd = hd; a.scale = scale;
+    D3PM_TRY(run_attention(cx, dt, a, 0, s));
+    LinearArgs g;
+    g.X = ws.att; g.ldx = d; g.W = b.attn_out_w; g.bias = b.attn_out_b; g.Y = ws.x; g.ldy = d;
+    g.R1 = ws.x; g.ldr = d; g.M = n; g.N = d; g.K = d; g.stats_out = ws.stats;
+    D3PM_TRY(run_linear(cx, dt, g, 0, s));
+    // ---- cross-attention: q_text | q_prompt are the two halves of ONE [n][2d] projection of x (the same q rows under norm2 / norm22)
+    D3PM_TRY(folded(f.q2_w, f.q2_s, f.q2_b, ws.qkv, 2 * d, ACT_NONE));
+    {
+      const void* kvt = at(kv_text, static_cast<size_t>(l) * batch * sh.s_text * 2 * d, es);
+      const void* kvp = at(kv_prompt, static_cast<size_t>(l) * batch * sh.s_prompt * 2 * d, es);
+      a = AttnArgs();
+      a.Q = ws.qkv; a.ldq = 2 * d; a.K = kvt; a.V = at(kvt, d, es); a.ldkv = 2 * d; a.O = ws.att; a.ldo = d;
+      a.B = batch; a.Tq = T; a.S = sh.s_text; a.H = H; a.hd = hd; a.scale = scale;
+      a.Q2 = at(ws.qkv, d, es); a.K2 = kvp; a.V2 = at(kvp, d, es); a.O2 = ws.att2; a.S2 = sh.s_prompt;
+      D3PM_TRY(run_attention(cx, dt, a, 0, s));
+    }
+    // ---- x = (x + o_text) + o_prompt, rounded at each add like the eager sum ----
+    g = LinearArgs();
+    g.X = ws.att; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
+    g.M = n; g.N = d; g.K = d; g.stats_out = ws.stats;
+    if ((tune_of(sh.tuning).row_panel & 8) && tune_of(sh.tuning).gemm_variant == 0 && panel64_dual_supported(dt, g, ws.att2)) {
+      g.tune = cx.tune;      // one or two utterances: both products through one resident weight panel (same bits as the two launches)
+      ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * 2.0 * g.M * g.N * g.K, es * (2.0 * g.M * g.K + static_cast<double>(g.N) * g.K + 2.0 * g.M * g.N));
+      D3PM_TRY(panel64_dual(dt, g, ws.att2, s));
+    } else {
+      g.Y = ws.h; g.R1 = nullptr; g.stats_out = nullptr;          // o_text -> h (free: no LayerNorm output lives there any more)
+      D3PM_TRY(run_linear(cx, dt, g, 0, s));
+      g = LinearArgs();
+      g.X = ws.att2; g.ldx = d; g.W = b.cross_out_w; g.bias = b.cross_out_b; g.Y = ws.x; g.ldy = d;
+      g.R1 = ws.x; g.R2 = ws.h; g.ldr = d; g.M = n; g.N = d; g.K = d; g.stats_out = ws.stats;
+      D3PM_TRY(run_linear(cx, dt, g, 0, s));
+    }
+    // ---- FiLM-modulated MLP: the (layer, t) copy of fc1 carries norm3 and the modulation ----
+    const size_t tn = static_cast<size_t>(t) * 4 * d;
+    D3PM_TRY(folded(at(f.fc1_w, tn * d, es), f.fc1_s + tn, f.fc1_b + tn, ws.mlp, 4 * d, ACT_GELU));
+    g = LinearArgs();
+    g.X = ws.mlp; g.ldx = 4 * d; g.W = b.fc2_w; g.bias = b.fc2_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
+    g.row_mask = frame_mask; g.mask_period = T; g.M = n; g.N = d; g.K = 4 * d; g.stats_out = ws.stats;
+    D3PM_TRY(run_linear(cx, dt, g, 0, s));
+  }
+  return D3PM_OK;
+}
+
 // hidden state after `layers` blocks is left in ws.x
 static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batch, const int32_t* x_t,
                            const uint8_t* frame_mask, int t, const void* film, const void* kv_text,
@@ -222,13 +301,14 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
                  D3PM_E_SHAPE, "fp8 fast path needs d_model = 512, a 16-bit model dtype and batch * canvas (%d) a multiple of 192", n);
   }
   // MX operands of the LayerNorm-fed projections live where the 16-bit LayerNorm outputs would: codes [2n][512] fill ws.h.
-  // The shared qkv | q | hidden | logits region (n x 4d elements = 4096 n bytes) also holds: fc1's MX output, codes [n][2048] at
-  // its start and scales [n][64] at byte 2048 n; the LayerNorm block scales [2n][16] at byte 3072 n -- beyond everything that is
-  // written there while they are read (packed qkv rows end at 3072 n, the queries at 2048 n, the hidden layer at 2112 n)
+  // The shared qkv | q | hidden | logits region (n x 4d elements = 4096 n bytes) also holds fc1's MX output: codes [n][2048] at
+  // its start and scales [n][64] at byte 2048 n.  The LayerNorm block scales [2n][16] have a workspace slot of their own (ws.mxs):
+  // they are read by a persistent GEMM for the whole launch, so they must not share bytes with anything that launch writes (a
+  // 16-bit fc1 output [n][2048] x 2 B covers the whole shared region).
   uint8_t* x8 = reinterpret_cast<uint8_t*>(ws.h);
   uint8_t* h8 = reinterpret_cast<uint8_t*>(ws.mlp);
   uint8_t* sh8 = h8 + static_cast<size_t>(n) * 4 * d;
-  uint8_t* sx8 = h8 + static_cast<size_t>(n) * 6 * d;
+  uint8_t* sx8 = ws.mxs;
   auto mx_gemm = [&](const uint8_t* X8, int ldx8, const uint8_t* SX8, const void* W8, const void* SW8, const void* bias, void* Y, int ldy,
                      const void* R1, const uint8_t* mask, int period, uint8_t* Y8, uint8_t* SY, int M, int N, int K, int act) -> int {
     MxLinearArgs m;
@@ -240,6 +320,11 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
     return mx_linear(dt, m, s);
   };
   const float scale = static_cast<float>(std::sqrt(1.0 / static_cast<double>(hd)));
+
+  // LayerNorm folded into the projections (d3pm_tuning.ln_fold, d3pm_fold_block): every LayerNorm-fed projection reads the raw
+  // residual stream and normalises in its epilogue; every projection that lands on the residual stream leaves the row moments
+  if (!use8 && w.fold && tune_of(sh.tuning).ln_fold && !(flags & D3PM_FLAG_FORCE_GENERIC) && fold_shape_ok(dt, d))
+    return denoiser_blocks_folded(sh, w, batch, x_t, frame_mask, t, kv_text, kv_prompt, ws, layers, s);
 
   EmbedArgs e;
   e.tokens = x_t; e.frame_mask = frame_mask; e.canvas = T; e.table = w.resps_emb; e.Y = ws.x;
@@ -490,6 +575,94 @@ int d3pm_film_table(const d3pm_shape* sh, const d3pm_weights* w, void* film, voi
     D3PM_TRY(generic_linear(sh->dtype, g, static_cast<hipStream_t>(stream)));
   }
   return D3PM_OK;
+}
+
+// ---- LayerNorm folded into the projections: the tables ---------------------------------------------------------------
+struct FoldLayout { size_t qkv_w, q2_w, fc1_w, qkv_s, qkv_b, q2_s, q2_b, fc1_s, fc1_b, per_layer; };
+static FoldLayout fold_layout(const d3pm_shape& sh) {
+  const size_t es = dtype_size(sh.dtype), d = sh.d_model, nt = static_cast<size_t>(sh.timesteps) + 1;
+  FoldLayout L{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at_ = off; off += align256(bytes); return at_; };
+  L.qkv_w = take(3 * d * d * es); L.q2_w = take(2 * d * d * es); L.fc1_w = take(nt * 4 * d * d * es);
+  L.qkv_s = take(3 * d * 4); L.qkv_b = take(3 * d * 4); L.q2_s = take(2 * d * 4); L.q2_b = take(2 * d * 4);
+  L.fc1_s = take(nt * 4 * d * 4); L.fc1_b = take(nt * 4 * d * 4);
+  L.per_layer = off;
+  return L;
+}
+
+size_t d3pm_fold_bytes(const d3pm_shape* sh) {
+  if (check_shape(sh, 1) != D3PM_OK || !fold_shape_ok(sh->dtype, sh->d_model)) return 0;
+  return fold_layout(*sh).per_layer * static_cast<size_t>(sh->n_layers);
+}
+
+int d3pm_fold_build(const d3pm_shape* sh, const d3pm_weights* w, const void* film, void* storage, size_t storage_bytes,
+                    d3pm_fold_block* out, void* stream) {
+  D3PM_TRY(check_shape(sh, 1));
+  D3PM_REQUIRE(w && w->blocks && film && storage && out, D3PM_E_ARG, "d3pm_fold_build: null pointer");
+  D3PM_REQUIRE(fold_shape_ok(sh->dtype, sh->d_model), D3PM_E_SHAPE, "d3pm_fold_build: needs a 16-bit dtype and d_model a multiple of 256");
+  const FoldLayout L = fold_layout(*sh);
+  D3PM_REQUIRE(storage_bytes >= L.per_layer * sh->n_layers, D3PM_E_WORKSPACE, "d3pm_fold_build: storage %zu < required %zu", storage_bytes,
+               L.per_layer * static_cast<size_t>(sh->n_layers));
+  D3PM_REQUIRE(reinterpret_cast<uintptr_t>(storage) % 256 == 0, D3PM_E_ARG, "d3pm_fold_build: storage must be 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int dt = sh->dtype, d = sh->d_model, nt = sh->timesteps + 1;
+  const size_t es = dtype_size(dt);
+  for (int l = 0; l < sh->n_layers; ++l) {
+    const d3pm_block_weights& b = w->blocks[l];
+    char* base = static_cast<char*>(storage) + L.per_layer * l;
+    auto f32 = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    D3PM_TRY(fold_rows_launch(dt, b.attn_in_w, b.attn_in_b, b.norm1_w, b.norm1_b, nullptr, 0, 3 * d, 1, d, base + L.qkv_w, f32(L.qkv_s), f32(L.qkv_b), s));
+    // cross_attn's q rows under norm2 (text queries) and under norm22 (prompt queries): the two halves of one [2d][d] operand
+    D3PM_TRY(fold_rows_launch(dt, b.cross_in_w, b.cross_in_b, b.norm2_w, b.norm2_b, nullptr, 0, d, 1, d, base + L.q2_w, f32(L.q2_s), f32(L.q2_b), s));
+    D3PM_TRY(fold_rows_launch(dt, b.cross_in_w, b.cross_in_b, b.norm22_w, b.norm22_b, nullptr, 0, d, 1, d, base + L.q2_w + static_cast<size_t>(d) * d * es,
+                              f32(L.q2_s) + d, f32(L.q2_b) + d, s));
+    // fc1 under norm3 + FiLM(t): film[t][l] = (scale | shift), rows strided by n_layers * 2d
+    D3PM_TRY(fold_rows_launch(dt, b.fc1_w, b.fc1_b, b.norm3_w, b.norm3_b, at(film, static_cast<size_t>(l) * 2 * d, es),
+                              static_cast<long>(sh->n_layers) * 2 * d, 4 * d, nt, d, base + L.fc1_w, f32(L.fc1_s), f32(L.fc1_b), s));
+    d3pm_fold_block& o = out[l];
+    o.qkv_w = base + L.qkv_w; o.qkv_s = f32(L.qkv_s); o.qkv_b = f32(L.qkv_b);
+    o.q2_w = base + L.q2_w; o.q2_s = f32(L.q2_s); o.q2_b = f32(L.q2_b);
+    o.fc1_w = base + L.fc1_w; o.fc1_s = f32(L.fc1_s); o.fc1_b = f32(L.fc1_b);
+  }
+  return D3PM_OK;
+}
+
+int d3pm_op_fold_weights(int dtype, const void* W, const void* bias, const void* gamma, const void* beta, const void* film, int N, int K,
+                         void* Wf, float* fold_s, float* fold_b, void* stream) {
+  D3PM_REQUIRE(W && gamma && beta && Wf && fold_s && fold_b && N > 0 && K > 0 && K % 8 == 0 && (dtype == D3PM_F16 || dtype == D3PM_BF16),
+               D3PM_E_ARG, "d3pm_op_fold_weights: bad arguments");
+  return fold_rows_launch(dtype, W, bias, gamma, beta, film, 0, N, 1, K, Wf, fold_s, fold_b, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_op_row_stats(int dtype, const void* X, int ldx, int M, int d, float* stats, void* stream) {
+  D3PM_REQUIRE(X && stats && M > 0 && d > 0 && d % 32 == 0 && ldx % 8 == 0 && (dtype == D3PM_F16 || dtype == D3PM_BF16), D3PM_E_ARG,
+               "d3pm_op_row_stats: bad arguments");
+  return row_stats_launch(dtype, X, ldx, M, d, stats, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_op_linear_stats(int dtype, const void* X, int ldx, const void* W, const void* bias, void* Y, int ldy, const void* R1,
+                         const void* R2, int ldr, const uint8_t* row_mask, int mask_period, int M, int N, int K, float* stats_out,
+                         const d3pm_tuning* tuning, void* stream) {
+  D3PM_REQUIRE(X && W && Y && R1 && stats_out && M > 0 && N > 0 && K > 0, D3PM_E_ARG, "d3pm_op_linear_stats: bad arguments");
+  LinearArgs g;
+  g.tune = tuning;
+  g.X = X; g.ldx = ldx; g.W = W; g.bias = bias; g.Y = Y; g.ldy = ldy; g.R1 = R1; g.R2 = R2; g.ldr = ldr;
+  g.row_mask = row_mask; g.mask_period = mask_period > 0 ? mask_period : 1; g.M = M; g.N = N; g.K = K; g.stats_out = stats_out;
+  D3PM_REQUIRE(mfma_linear_supported(dtype, g), D3PM_E_SHAPE, "d3pm_op_linear_stats: needs the MFMA family (16-bit, K %% 64 == 0, N %% 32 == 0)");
+  return mfma_linear(dtype, g, static_cast<hipStream_t>(stream));
+}
+
+int d3pm_op_linear_fold(int dtype, const void* X, int ldx, const void* Wf, const float* fold_s, const float* fold_b, const float* stats_in,
+                        float eps, void* Y, int ldy, int M, int N, int K, int act, const d3pm_tuning* tuning, void* stream) {
+  D3PM_REQUIRE(X && Wf && fold_s && fold_b && stats_in && Y && M > 0 && N > 0 && K > 0, D3PM_E_ARG, "d3pm_op_linear_fold: bad arguments");
+  LinearArgs g;
+  g.tune = tuning;
+  g.X = X; g.ldx = ldx; g.W = Wf; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.act = act;
+  g.fold_s = fold_s; g.fold_b = fold_b; g.stats_in = stats_in; g.fold_eps = eps;
+  D3PM_REQUIRE(mfma_linear_supported(dtype, g), D3PM_E_SHAPE,
+               "d3pm_op_linear_fold: needs the MFMA family (16-bit), K a multiple of 256, N of 4, act 0 / 1 and 16-byte aligned tables");
+  return mfma_linear(dtype, g, static_cast<hipStream_t>(stream));
 }
 
 int d3pm_cond_kv(const d3pm_shape* sh, const d3pm_weights* w, int batch, const void* cond_text, const void* cond_prompt,
@@ -1018,10 +1191,10 @@ int d3pm_prof_create(int kclass, int max_events, d3pm_prof** out) {
   D3PM_REQUIRE(p, D3PM_E_ARG, "d3pm_prof_create: out of host memory");
   p->ev.resize(static_cast<size_t>(max_events) * 2);
   p->cls.assign(static_cast<size_t>(max_events), -1);
-  for (auto& e : p->ev) {
-    if (hipEventCreate(&e) != hipSuccess) {
+  for (size_t i = 0; i < p->ev.size(); ++i) {
+    if (hipEventCreate(&p->ev[i]) != hipSuccess) {
       set_error("d3pm_prof_create: hipEventCreate failed");
-      p->ev.clear();
+      for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(p->ev[j]);     // the events created so far
       delete p;
       return D3PM_E_HIP;
     }

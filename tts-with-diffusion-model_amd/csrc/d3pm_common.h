@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/d3pm_hip.h"
 
 namespace d3pm {
@@ -128,5 +130,24 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 inline size_t dtype_size(int dtype) { return dtype == D3PM_F32 ? 4 : 2; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (kernel, device) pair.  Every launch site keeps one bit per device of the
+// process (an idempotent memo, set with atomics: two threads racing on it both set the attribute, which is harmless) so that a
+// process driving several GPUs sets it on each of them and the common case costs one relaxed load.
+inline hipError_t lds_attr_for_device(const void* fn, size_t bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+#define D3PM_LDS_ATTR(fn, bytes)                                                                              \
+  do {                                                                                                        \
+    static std::atomic<uint64_t> lds_attr_done_{0};                                                           \
+    D3PM_CHECK_HIP(::d3pm::lds_attr_for_device(reinterpret_cast<const void*>(fn), (bytes), lds_attr_done_)); \
+  } while (0)
 
 }  // namespace d3pm

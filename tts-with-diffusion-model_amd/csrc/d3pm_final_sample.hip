@@ -132,12 +132,7 @@ int final_sample(int dtype, const void* X, int ldx, const void* W, const void* b
   const size_t lds = static_cast<size_t>(FS_ROWS) * FS_ZLD * 2;
 #define D3PM_FS(U)                                                                                                        \
   do {                                                                                                                    \
-    static bool attr_set = false;                                                                                         \
-    if (!attr_set) {                                                                                                      \
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&final_sample_fused<U>),                           \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                         \
-      attr_set = true;                                                                                                    \
-    }                                                                                                                     \
+    D3PM_LDS_ATTR((&final_sample_fused<U>), 80 * 1024);                                                                   \
     final_sample_fused<U><<<grid, block, lds, s>>>(static_cast<const U*>(X), ldx, static_cast<const U*>(W),               \
                                                    static_cast<const U*>(bias), a.x_t, a.x_next, a.x_next2, a.rows, d,    \
                                                    a.mask_id, a.seed, a.seed_hbm, a.row0, a.greedy, a.pc);                \

@@ -1,0 +1,160 @@
+// d3pm_fold.hip -- LayerNorm folded into the projection that consumes it: weight preparation and the row-moment producers
+// that are not GEMM epilogues.
+//
+// DiTBlock.forward applies every LayerNorm directly in front of a Linear (/root/reference/vall_e/vall_e/ar_discrete.py:131-132
+// norm1 -> attn in-projection, :136-142 norm2 | norm22 -> cross_attn's query rows, :145-159 norm3 + FiLM -> mlp.fc1), so
+//     LN(x) W^T + b = rstd_r (x_r . W'^T - mean_r s) + b',   W' = W o gamma,  s_n = sum_k W'[n][k],  b' = W beta + b
+// (d3pm_mfma_tile.h, EPI_LNF).  With FiLM the per-column factor is gamma_k rn(1 + scale_t[k]) and the constant
+// beta_k rn(1 + scale_t[k]) + shift_t[k]: it depends on the timestep, so fc1 gets one W' per (layer, t) -- (timesteps + 1) x
+// 4d x d elements per layer, 1.27 GB for the 100-step d = 512 model, built once per weight set next to d3pm_film_table and read
+// at 2 MB per launch.  W' is rounded to the storage type once here; s is summed over the ROUNDED W' (so that
+// x . W' - mean s cancels exactly what the matrix pipe accumulated), b' over the unrounded products, both in fp32.
+#include "d3pm_kernels.h"
+
+namespace d3pm {
+namespace {
+
+template <typename T> struct Vec8 { T v[8]; };
+
+// one wave per output row (t, n): W row n [K], gamma / beta [K], optional FiLM row film + t * film_ld = (scale [K] | shift [K])
+template <typename T>
+__global__ __launch_bounds__(256) void fold_rows(const T* __restrict__ W, const T* __restrict__ bias, const T* __restrict__ gamma,
+                                                 const T* __restrict__ beta, const T* __restrict__ film, long film_ld, int n_rows,
+                                                 int n_t, int K, T* __restrict__ Wf, float* __restrict__ s_out, float* __restrict__ b_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long r = static_cast<long>(blockIdx.x) * 4 + wave;
+  if (r >= static_cast<long>(n_rows) * n_t) return;
+  const int t = static_cast<int>(r / n_rows), n = static_cast<int>(r % n_rows);
+  const T* wrow = W + static_cast<size_t>(n) * K;
+  const T* frow = film ? film + static_cast<size_t>(t) * film_ld : nullptr;
+  T* orow = Wf + static_cast<size_t>(r) * K;
+  float s = 0.f, b = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const Vec8<T> w8 = *reinterpret_cast<const Vec8<T>*>(wrow + k), g8 = *reinterpret_cast<const Vec8<T>*>(gamma + k),
+                  b8 = *reinterpret_cast<const Vec8<T>*>(beta + k);
+    Vec8<T> sc8{}, sh8{}, o8;
+    if (frow) { sc8 = *reinterpret_cast<const Vec8<T>*>(frow + k); sh8 = *reinterpret_cast<const Vec8<T>*>(frow + K + k); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float w = static_cast<float>(w8.v[i]);
+      float g = static_cast<float>(g8.v[i]), c = static_cast<float>(b8.v[i]);
+      if (frow) {                         // FiLM as the eager model applies it: (1 + scale) rounded to the storage type first (:146-156)
+        const float gg = rn<T>(1.0f + static_cast<float>(sc8.v[i]));
+        g *= gg;
+        c = __builtin_fmaf(c, gg, static_cast<float>(sh8.v[i]));
+      }
+      o8.v[i] = static_cast<T>(w * g);
+      s += static_cast<float>(o8.v[i]);
+      b = __builtin_fmaf(w, c, b);
+    }
+    *reinterpret_cast<Vec8<T>*>(orow + k) = o8;
+  }
+  s = wave_sum(s);
+  b = wave_sum(b);
+  if (lane == 0) {
+    s_out[r] = s;
+    b_out[r] = b + (bias ? static_cast<float>(bias[n]) : 0.f);
+  }
+}
+
+// (sum, sum of squares) of every 32-column part of every row: stats[M][d / 32][2].  One wave per row, lane L of pass j owns the
+// 16-byte chunk 64 j + L; the four lanes of a quad own one part.  Used where the residual rows do not come out of a GEMM epilogue:
+// the token embedding in front of the first block (ar_discrete.py:753), and as a stand-alone op for tests.
+template <typename T>
+__device__ __forceinline__ void part_moments(const Vec8<T>& raw, float& a, float& q) {
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(raw.v[i]);
+  a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  q = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+  // the order of the GEMM epilogues (d3pm_mfma_tile.h emit_stats: columns 0-7 + 16-23, then + (8-15 + 24-31)), so that the moments
+  // of a row are the same bits whichever kernel produced them
+  a = add_dpp<0x4E>(a); q = add_dpp<0x4E>(q);     // lane ^ 2
+  a = add_dpp<0xB1>(a); q = add_dpp<0xB1>(q);     // lane ^ 1
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_stats(const T* __restrict__ x, int ldx, int M, int d, float* __restrict__ stats) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  const int parts = d >> 5;
+  for (int c = lane; c < (d >> 3); c += kWave) {
+    const Vec8<T> raw = *reinterpret_cast<const Vec8<T>*>(x + static_cast<size_t>(row) * ldx + c * 8);
+    float a, q;
+    part_moments(raw, a, q);
+    if ((lane & 3) == 0) *reinterpret_cast<float2v*>(stats + (static_cast<size_t>(row) * parts + (c >> 2)) * 2) = float2v{a, q};
+  }
+}
+
+// embed_rows_vec (d3pm_generic.hip) + the moments of the gathered rows in the same pass
+template <typename T>
+__global__ __launch_bounds__(256) void embed_rows_stats(const int32_t* __restrict__ tok, const uint8_t* __restrict__ frame_mask,
+                                                        int canvas, const T* __restrict__ table, T* __restrict__ y, int M, int d,
+                                                        int n_classes, float* __restrict__ stats) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  int id = tok[row];
+  id = id < 0 ? 0 : (id >= n_classes ? n_classes - 1 : id);
+  const bool live = frame_mask[row % canvas] != 0;
+  const Vec8<T>* src = reinterpret_cast<const Vec8<T>*>(table + static_cast<size_t>(id) * d);
+  Vec8<T>* dst = reinterpret_cast<Vec8<T>*>(y + static_cast<size_t>(row) * d);
+  const int parts = d >> 5;
+  for (int c = lane; c < (d >> 3); c += kWave) {
+    Vec8<T> raw = src[c];
+    if (!live) raw = Vec8<T>{};
+    dst[c] = raw;
+    float a, q;
+    part_moments(raw, a, q);
+    if ((lane & 3) == 0) *reinterpret_cast<float2v*>(stats + (static_cast<size_t>(row) * parts + (c >> 2)) * 2) = float2v{a, q};
+  }
+}
+
+}  // namespace
+
+bool fold_shape_ok(int dtype, int d) { return (dtype == D3PM_F16 || dtype == D3PM_BF16) && d >= 256 && d % 256 == 0; }
+
+int fold_rows_launch(int dtype, const void* W, const void* bias, const void* gamma, const void* beta, const void* film, long film_ld,
+                     int n_rows, int n_t, int K, void* Wf, float* s_out, float* b_out, hipStream_t s) {
+  const long rows = static_cast<long>(n_rows) * n_t;
+  const dim3 grid(static_cast<unsigned>((rows + 3) / 4)), block(256);
+  if (dtype == D3PM_F16)
+    fold_rows<f16><<<grid, block, 0, s>>>(static_cast<const f16*>(W), static_cast<const f16*>(bias), static_cast<const f16*>(gamma),
+                                          static_cast<const f16*>(beta), static_cast<const f16*>(film), film_ld, n_rows, n_t, K,
+                                          static_cast<f16*>(Wf), s_out, b_out);
+  else
+    fold_rows<bf16><<<grid, block, 0, s>>>(static_cast<const bf16*>(W), static_cast<const bf16*>(bias), static_cast<const bf16*>(gamma),
+                                           static_cast<const bf16*>(beta), static_cast<const bf16*>(film), film_ld, n_rows, n_t, K,
+                                           static_cast<bf16*>(Wf), s_out, b_out);
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+int row_stats_launch(int dtype, const void* x, int ldx, int M, int d, float* stats, hipStream_t s) {
+  const dim3 grid(static_cast<unsigned>((M + 3) / 4)), block(256);
+  if (dtype == D3PM_F16) row_stats<f16><<<grid, block, 0, s>>>(static_cast<const f16*>(x), ldx, M, d, stats);
+  else row_stats<bf16><<<grid, block, 0, s>>>(static_cast<const bf16*>(x), ldx, M, d, stats);
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+int embed_tokens_stats(int dtype, const EmbedArgs& a, float* stats, hipStream_t s) {
+  if (a.n_q > 1) {                 // level-summed rows (extension): the generic gather, then the moments of the rows it wrote
+    int rc = embed_tokens(dtype, a, s);
+    return rc != D3PM_OK ? rc : row_stats_launch(dtype, a.Y, a.d, a.M, a.d, stats, s);
+  }
+  const dim3 grid(static_cast<unsigned>((a.M + 3) / 4)), block(256);
+  if (dtype == D3PM_F16)
+    embed_rows_stats<f16><<<grid, block, 0, s>>>(a.tokens, a.frame_mask, a.canvas, static_cast<const f16*>(a.table), static_cast<f16*>(a.Y),
+                                                 a.M, a.d, a.n_classes, stats);
+  else
+    embed_rows_stats<bf16><<<grid, block, 0, s>>>(a.tokens, a.frame_mask, a.canvas, static_cast<const bf16*>(a.table),
+                                                  static_cast<bf16*>(a.Y), a.M, a.d, a.n_classes, stats);
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+}  // namespace d3pm

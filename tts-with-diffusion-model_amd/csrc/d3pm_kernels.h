@@ -15,7 +15,7 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SILU = 3 };
 inline const d3pm_tuning& tune_of(const d3pm_tuning* t) {
   static const d3pm_tuning kDefault = {/*gemm_variant*/ 0, /*gemm_persist_slots*/ 1024, /*lat_tile*/ 0, /*attn_query_groups*/ 0,
                                        /*attn_pair_sequential*/ 1, /*attn_cross_resident*/ 1, /*row_panel*/ 10, /*workspace_alias*/ 1,
-                                       /*prof*/ nullptr};
+                                       /*regime_batch*/ 0, /*ln_fold*/ 1, /*prof*/ nullptr};
   return t ? *t : kDefault;
 }
 
@@ -40,7 +40,26 @@ struct LinearArgs {
   int M = 0, N = 0, K = 0;
   int act = ACT_NONE;
   const d3pm_tuning* tune = nullptr;
+  // LayerNorm folded into this projection (MFMA family only, d3pm_mfma_tile.h): X = the raw residual rows [M][K = d_model], W = W o gamma,
+  // `bias` unused; v = rn(rstd_r (acc - mean_r fold_s[n]) + fold_b[n]) [then act] with the row moments from stats_in [M][K / 32][2]
+  const float* fold_s = nullptr; const float* fold_b = nullptr; const float* stats_in = nullptr; float fold_eps = 1e-6f;
+  // moments of the rows this launch stores (N = d_model, after residual / mask): stats_out [M][N / 32][2] partial (sum, sum of squares)
+  float* stats_out = nullptr;
 };
+// which LayerNorm-fold combinations the MFMA epilogues instantiate: LNF [+ GELU] without residual / mask; STATS with R1, R1 + R2, R1 + mask
+inline bool fold_args_ok(const LinearArgs& a) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; };
+  if (a.fold_s) {
+    if (!a.fold_b || !a.stats_in || a.R1 || a.row_mask || a.stats_out || (a.act != ACT_NONE && a.act != ACT_GELU)) return false;
+    if (a.K % 256 != 0 || a.N % 4 != 0 || !al16(a.fold_s) || !al16(a.fold_b) || !al16(a.stats_in)) return false;
+  } else if (a.fold_b || a.stats_in) {
+    return false;
+  }
+  if (a.stats_out) {
+    if (!a.R1 || a.act != ACT_NONE || a.N % 32 != 0 || (reinterpret_cast<uintptr_t>(a.stats_out) % 8) != 0) return false;
+  }
+  return true;
+}
 
 // O[b][i][h*hd+c] = sum_j P[i][j] V[b][j][h*hd+c],  P = rn(softmax(rn(rn(q*scale) . k)))
 // element (b, row, h, c) of Q lives at Q + (b*Tq+row)*ldq + h*hd + c; K/V likewise with S, ldkv.
@@ -180,6 +199,13 @@ bool fast_layernorm_supported(int dtype, const LayerNormArgs& a);
 int fast_layernorm(int dtype, const LayerNormArgs& a, hipStream_t s);
 
 PosteriorConsts make_posterior_consts(const d3pm_schedule* sched, int t);
+
+// LayerNorm folded into the projections (d3pm_fold.hip): weight preparation and the non-GEMM producers of row moments
+bool fold_shape_ok(int dtype, int d);
+int fold_rows_launch(int dtype, const void* W, const void* bias, const void* gamma, const void* beta, const void* film, long film_ld,
+                     int n_rows, int n_t, int K, void* Wf, float* s_out, float* b_out, hipStream_t s);
+int row_stats_launch(int dtype, const void* x, int ldx, int M, int d, float* stats, hipStream_t s);
+int embed_tokens_stats(int dtype, const EmbedArgs& a, float* stats, hipStream_t s);
 
 // ---- stock NAR model (levels 1..7): input assembly, AdaLN, temperature sampling (d3pm_nar.hip) ----
 struct NarEmbedArgs {

@@ -698,7 +698,8 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
   // utterances x 768 frames, 19.5 vs 20.3 at 32 x 384, 28.8 vs 30.8 at 16 x 768; tests/ab_attn32.py); below that the 64-query
   // workgroups of the kernel below finish sooner.  attn_query_groups: 0 auto, 32 always, 33 always and the plain walk, 1 / 2 never.
   {
-    const long long wgs32 = static_cast<long long>(a.Tq / 128) * a.H * a.B;
+    // regime_batch: the batch the automatic choice is made for (a shard of a split batch takes the kernels of the whole batch)
+    const long long wgs32 = static_cast<long long>(a.Tq / 128) * a.H * (tn.regime_batch > 0 ? tn.regime_batch : a.B);
     const int q = tn.attn_query_groups;
 #ifdef D3PM_ABLATIONS
     const bool arm35 = q == 35;      // A/B library: the pipelined kernel with 192-query workgroups (d3pm_mfma_attn32.hip)
@@ -707,7 +708,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
 #endif
     if ((q == 32 || q == 33 || arm35 || (q == 0 && wgs32 >= 512)) && mfma_attention32_supported(dtype, a)) return mfma_attention32(dtype, a, s);
   }
-  const long long cross_wgs = static_cast<long long>((a.Tq + 255) / 256) * a.H * a.B;
+  const long long cross_wgs = static_cast<long long>((a.Tq + 255) / 256) * a.H * (tn.regime_batch > 0 ? tn.regime_batch : a.B);
   if ((g_attn_cross_resident >= 2 || (g_attn_cross_resident == 1 && cross_wgs >= 256)) && a.Q2 != nullptr && a.key_len == nullptr &&
       a.S <= BKV && a.S2 <= 4 * BKV) {
     const int n_qblocks = (a.Tq + 255) / 256;
@@ -725,12 +726,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     const size_t lds = static_cast<size_t>(1 + (a.S2 + BKV - 1) / BKV) * 2 * TILE;
 #define D3PM_CROSS(T, PIPE)                                                                                                  \
     do {                                                                                                                     \
-      static bool attr_set = false;                                                                                          \
-      if (!attr_set) {                                                                                                       \
-        D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_cross_hd64<T, PIPE>),                         \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 2 * TILE));                       \
-        attr_set = true;                                                                                                     \
-      }                                                                                                                      \
+      D3PM_LDS_ATTR((&attn_cross_hd64<T, PIPE>), 5 * 2 * TILE);                                                              \
       attn_cross_hd64<T, PIPE><<<grid, block, lds, s>>>(static_cast<const T*>(a.Q), static_cast<const T*>(a.K),               \
           static_cast<const T*>(a.V), static_cast<T*>(a.O), a.S, static_cast<const T*>(a.Q2), static_cast<const T*>(a.K2),    \
           static_cast<const T*>(a.V2), static_cast<T*>(a.O2), a.S2, a.ldq, a.ldkv, a.ldo, a.Tq, a.scale, a.H, n_qblocks, n_qsplit); \
@@ -774,12 +770,7 @@ int mfma_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     D3PM_ATTN(bf16, 3, false);
   } else if (g_attn_qg >= 200 && dtype == D3PM_BF16 && !a.Q2) {      // occupancy probe: the shipped QG = 2 kernel with idle dynamic LDS
     const size_t pad = g_attn_qg == 201 ? 32 * 1024 : 96 * 1024;   // 201: two workgroups per CU, 202: one (three without)
-    static bool attr_set = false;
-    if (!attr_set) {
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_hd64<bf16, 2, false, 0>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      attr_set = true;
-    }
+    D3PM_LDS_ATTR((&attn_mfma_hd64<bf16, 2, false, 0>), 96 * 1024);
     attn_mfma_hd64<bf16, 2, false, 0><<<grid, block, pad, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K),
         static_cast<const bf16*>(a.V), a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks, nullptr, nullptr, nullptr,
         nullptr, 0, n_first, a.key_len);

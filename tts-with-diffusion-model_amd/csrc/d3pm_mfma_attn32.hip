@@ -835,11 +835,7 @@ int mfma_attention32_cross(int dtype, const AttnArgs& a, int n_qsplit, hipStream
   const size_t lds = static_cast<size_t>(1 + (a.S2 + BKV - 1) / BKV) * 2 * TILE;
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_cross_hd64<U>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 2 * TILE));
-      attr_set = true;
-    }
+    D3PM_LDS_ATTR((&attn32_cross_hd64<U>), 5 * 2 * TILE);
     attn32_cross_hd64<U><<<grid, block, lds, s>>>(static_cast<const U*>(a.Q), static_cast<const U*>(a.K), static_cast<const U*>(a.V),
                                                   static_cast<U*>(a.O), a.S, static_cast<const U*>(a.Q2), static_cast<const U*>(a.K2),
                                                   static_cast<const U*>(a.V2), static_cast<U*>(a.O2), a.S2, a.ldq, a.ldkv, a.ldo, a.Tq,
@@ -857,12 +853,8 @@ int mfma_attention32(int dtype, const AttnArgs& a, hipStream_t s) {
   if (ab_knobs().attn_arm >= 321 && ab_knobs().attn_arm <= 324 && dtype == D3PM_BF16) {      // coarse stamps: 321 the plain walk, 322 the pipelined one; 323 / 324: the same at ONE workgroup per CU (idle dynamic LDS)
     const int arm = ab_knobs().attn_arm;
     const size_t pad = arm >= 323 ? 72 * 1024 : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_hd64<bf16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32p_hd64<bf16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      attr_set = true;
-    }
+    D3PM_LDS_ATTR((&attn32_hd64<bf16, 1>), 96 * 1024);
+    D3PM_LDS_ATTR((&attn32p_hd64<bf16, 1>), 96 * 1024);
     if (arm == 321 || arm == 323)
       attn32_hd64<bf16, 1><<<grid, block, pad, s>>>(static_cast<const bf16*>(a.Q), a.ldq, static_cast<const bf16*>(a.K), static_cast<const bf16*>(a.V),
                                                   a.ldkv, static_cast<bf16*>(a.O), a.ldo, a.Tq, a.S, a.scale, a.H, n_qblocks);

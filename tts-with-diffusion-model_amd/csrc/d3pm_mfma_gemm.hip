@@ -70,7 +70,7 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(256, 4) void gemm_mfma_128_glds(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                              const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                              const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                                             int mask_period, int M, int N, int K, int n_tiles) {
+                                                             int mask_period, int M, int N, int K, int n_tiles, EpiFold ef) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128_glds(const T* __restrict
     __syncthreads();
   }
 #ifndef D3PM_EXP_NOSTORE
-  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane, nullptr, nullptr, static_cast<const EpiPre<T, 4, 4>*>(nullptr), &ef);
 #else
   {  // ablation build (tests/bench_kernels.py), never shipped: keep every accumulator live, store nothing
     float sum = 0.f;
@@ -145,7 +145,7 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_128_pf(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                            const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                            const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
-                                                           int mask_period, int M, int N, int K, int n_tiles) {
+                                                           int mask_period, int M, int N, int K, int n_tiles, EpiFold ef) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_128_pf(const T* __restrict__
     __builtin_amdgcn_s_barrier();                        // barrier B: tile kt's buffer may be overwritten
   }
 #ifndef D3PM_EXP_NOSTORE
-  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane);
+  epilogue_store<T, EPI>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64, n0 + wn * 64, lane, nullptr, nullptr, static_cast<const EpiPre<T, 4, 4>*>(nullptr), &ef);
 #else
   {  // ablation build (tests/bench_kernels.py), never shipped: keep every accumulator live, store nothing
     float sum = 0.f;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128_persist(const T* __restr
                                                                 const T* __restrict__ bias, T* Y, int ldy, const T* R1,
                                                                 const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                                 int mask_period, int M, int N, int K, int n_tiles,
-                                                                int tiles_total) {
+                                                                EpiFold ef, int tiles_total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_128_persist(const T* __restr
       issue(sx, sw);
     }
     epilogue_store<T, EPI, 4, 4, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 64,
-                                       n0 + wn * 64, lane);
+                                       n0 + wn * 64, lane, nullptr, nullptr, static_cast<const EpiPre<T, 4, 4>*>(nullptr), &ef);
     if (!more) break;
     first = false;
   }
@@ -367,7 +367,8 @@ bool mfma_linear_supported(int dtype, const LinearArgs& a) {
   if (a.R2 && !aligned(a.R2, 16)) return false;
   if (static_cast<long long>(a.M) * a.N < 128 * 128) return false;     // not worth a 128^2 tile
   const bool gelu = a.act == ACT_GELU, r1 = a.R1 != nullptr, r2 = a.R2 != nullptr, mk = a.row_mask != nullptr;
-  if (a.act == ACT_RELU || a.act == ACT_SILU) return !r1 && !mk;   // condition-encoder FFN epilogues
+  if (!fold_args_ok(a)) return false;
+  if (a.act == ACT_RELU || a.act == ACT_SILU) return !r1 && !mk && !a.fold_s && !a.stats_out;   // condition-encoder FFN epilogues
   if (r2 && !r1) return false;
   // instantiated epilogues: plain, GELU, R1, R1+R2, R1+mask
   if (gelu && (r1 || mk)) return false;
@@ -424,20 +425,16 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   const int tiles_total = n_tiles * m_tiles, want = (tiles_total + 7) & ~7;
   const dim3 grid(static_cast<unsigned>(persist ? (want < g_persist_slots ? want : g_persist_slots) : tiles_total)), block(256);
   const int epi = (a.act == ACT_GELU ? EPI_GELU : a.act == ACT_RELU ? EPI_RELU : a.act == ACT_SILU ? EPI_SILU : 0) |
-                  (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
+                  (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0) | (a.fold_s ? EPI_LNF : 0) | (a.stats_out ? EPI_STATS : 0);
+  const EpiFold ef = epi_fold_of(a);
 
 #define D3PM_GEMM(KERNEL, ...)                                                                                  \
   do {                                                                                                          \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),                                \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));          \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
+    D3PM_LDS_ATTR((&KERNEL), 4 * TILE_BYTES);                                                                   \
     KERNEL<<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),             \
                                     static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,                 \
                                     static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr, a.row_mask, \
-                                    a.mask_period, a.M, a.N, a.K, n_tiles, ##__VA_ARGS__);                      \
+                                    a.mask_period, a.M, a.N, a.K, n_tiles, ef, ##__VA_ARGS__);                  \
     return D3PM_OK;                                                                                             \
   } while (0)
 #define D3PM_GEMM_EPI(E)                                                \
@@ -454,6 +451,11 @@ int mfma_linear(int dtype, const LinearArgs& a, hipStream_t s) {
       case EPI_R1: D3PM_GEMM_EPI(EPI_R1);
       case EPI_R2: D3PM_GEMM_EPI(EPI_R2);
       case EPI_R1 | EPI_MASK: D3PM_GEMM_EPI(EPI_R1 | EPI_MASK);
+      case EPI_LNF: D3PM_GEMM_EPI(EPI_LNF);                       // LayerNorm folded into the projection (d3pm_mfma_tile.h)
+      case EPI_LNF | EPI_GELU: D3PM_GEMM_EPI(EPI_LNF | EPI_GELU);
+      case EPI_R1 | EPI_STATS: D3PM_GEMM_EPI(EPI_R1 | EPI_STATS);   // residual rows + their moments for the next folded LayerNorm
+      case EPI_R2 | EPI_STATS: D3PM_GEMM_EPI(EPI_R2 | EPI_STATS);
+      case EPI_R1 | EPI_MASK | EPI_STATS: D3PM_GEMM_EPI(EPI_R1 | EPI_MASK | EPI_STATS);
       case EPI_RELU: D3PM_GEMM((gemm_mfma_128_glds<U, EPI_RELU>));
       case EPI_SILU: D3PM_GEMM((gemm_mfma_128_glds<U, EPI_SILU>));
       default: break;

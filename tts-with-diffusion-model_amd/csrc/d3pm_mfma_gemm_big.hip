@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
                                                         const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                         int mask_period, int M, int N, int K, int n_tiles,
                                                         int tiles_total, const uint16_t* __restrict__ gelu_tab_g,
-                                                        RowPanelArgs<T> rp) {
+                                                        RowPanelArgs<T> rp, EpiFold ef) {
   constexpr int NW = WM * WN, TM = 96 * WM, TN = 64 * WN;   // 8 waves: one workgroup per CU; 4 waves: two
   constexpr int XD = TM / 8, WD = TN / 8;              // 1-KiB DMA pieces (8 rows x 128 B) per k-step and operand
   constexpr int XPW = (XD + NW - 1) / NW, WPW = WD / NW;   // pieces per wave
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   constexpr bool kMx = (FUSE & FUSE_MX) != 0;
   static_assert(!kMx || kLn, "the MX output is the LayerNorm output");
   static_assert(FUSE == 0 || (WM == 1 && WN == 8 && !kDrip && (MODE & 1)), "row-panel fusion: 96 x 512 tiles, hand-placed schedule");
+  static_assert((EPI & (EPI_LNF | EPI_STATS)) == 0 || (FUSE == 0 && !kDrip && !kPreEpi), "the folded-LayerNorm epilogues ride in the plain launches");
   static_assert(!kLn2 || kLn, "the second LayerNorm shares the moments of the first");
   static_assert(!kDrip || kHand, "deferred stores ride in the hand-placed schedule");
   constexpr int SPS = 12 - NDMA;                        // deferred stores per k-step: the MFMA groups behind the last DMA piece
@@ -527,14 +528,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
         }
         }   // 16-bit LayerNorm outputs
       }
-    } else if (kDrip && more) {      // keep the finished tile in registers: its stores go out inside the next tile's first k-steps
-      epilogue_store<T, EPI, 4, 6, true, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
-                                               n0 + wn * 64, lane, pend, gelu_tab);
-      pend_y = Y + static_cast<size_t>(m0 + wm * 96 + (lane & 15)) * ldy + n0 + wn * 64 + epilogue_nq(lane);
-      pending = true;
     } else {
-      epilogue_store<T, EPI, 4, 6, true, false, (MODE & 512) != 0, kPreEpi>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
-                                                                            n0 + wn * 64, lane, nullptr, gelu_tab, &pre);
+      bool kept = false;
+      if constexpr (kDrip) {         // keep the finished tile in registers: its stores go out inside the next tile's first k-steps
+        if (more) {
+          epilogue_store<T, EPI, 4, 6, true, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
+                                                   n0 + wn * 64, lane, pend, gelu_tab);
+          pend_y = Y + static_cast<size_t>(m0 + wm * 96 + (lane & 15)) * ldy + n0 + wn * 64 + epilogue_nq(lane);
+          pending = true;
+          kept = true;
+        }
+      }
+      if (!kept)
+        epilogue_store<T, EPI, 4, 6, true, false, (MODE & 512) != 0, kPreEpi>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
+                                                                              n0 + wn * 64, lane, nullptr, gelu_tab, &pre, &ef);
     }
     if (!more) break;
     t = t_next;
@@ -579,6 +586,7 @@ int big_linear_tile(int dtype, const LinearArgs& a, int want) {
   if (a.ldx % 8 != 0 || a.ldy % 8 != 0 || !aligned16(a.X) || !aligned16(a.W) || !aligned16(a.Y)) return 0;
   if (a.R1 && (a.ldr % 8 != 0 || !aligned16(a.R1))) return 0;
   if (a.R2 && (!a.R1 || !aligned16(a.R2))) return 0;
+  if (!fold_args_ok(a)) return 0;
   const bool gelu = a.act == ACT_GELU, r1 = a.R1 != nullptr, r2 = a.R2 != nullptr, mk = a.row_mask != nullptr;
   if (a.act != ACT_NONE && !gelu) return 0;
   if (gelu && (r1 || mk)) return 0;                       // instantiated epilogues: plain, GELU, R1, R1+R2, R1+mask
@@ -636,16 +644,11 @@ static int big_launch(const LinearArgs& a, int n_tiles, int tiles_total, dim3 gr
     if (tab) lds += GELU_TAB_BYTES;
   }
 #endif
-  static bool attr_set = false;
-  if (!attr_set) {
-    D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_big<U, E, WM, WN, MD>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  D3PM_LDS_ATTR((&gemm_mfma_big<U, E, WM, WN, MD>), 160 * 1024);
   gemm_mfma_big<U, E, WM, WN, MD><<<grid, dim3(WM * WN * 64), lds, s>>>(
       static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
       static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles,
-      tiles_total, tab, RowPanelArgs<U>{});
+      tiles_total, tab, RowPanelArgs<U>{}, epi_fold_of(a));
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;
 }
@@ -711,6 +714,14 @@ static int big_launch_geometry(int id, const LinearArgs& a, int n_tiles, int til
 #endif
 }
 
+// the folded-LayerNorm epilogues (EPI_LNF / EPI_STATS, d3pm_mfma_tile.h) run on the shipped schedule of each geometry only
+template <typename U, int E>
+static int big_launch_fold(int id, const LinearArgs& a, int n_tiles, int tiles_total, dim3 grid, size_t lds, hipStream_t s) {
+  if (id == 1) return big_launch<U, E, 1, 8, 1>(a, n_tiles, tiles_total, grid, lds, s);
+  if (id == 2) return big_launch<U, E, 2, 4, 1>(a, n_tiles, tiles_total, grid, lds, s);
+  return big_launch<U, E, 2, 2, 1>(a, n_tiles, tiles_total, grid, lds, s);
+}
+
 int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s) {
   int tm, tn, waves;
   big_geometry(id, tm, tn, waves);
@@ -718,10 +729,16 @@ int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s) {
   const int slots = 256 * (8 / waves), want = (tiles_total + 7) & ~7;
   const dim3 grid(static_cast<unsigned>(want < slots ? want : slots));
   const size_t lds = 2 * static_cast<size_t>(tm + tn) * ROW_BYTES;
-  const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
+  const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0) |
+                  (a.fold_s ? EPI_LNF : 0) | (a.stats_out ? EPI_STATS : 0);
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
     switch (epi) {
+      case EPI_LNF: return big_launch_fold<U, EPI_LNF>(id, a, n_tiles, tiles_total, grid, lds, s);
+      case EPI_LNF | EPI_GELU: return big_launch_fold<U, EPI_LNF | EPI_GELU>(id, a, n_tiles, tiles_total, grid, lds, s);
+      case EPI_R1 | EPI_STATS: return big_launch_fold<U, EPI_R1 | EPI_STATS>(id, a, n_tiles, tiles_total, grid, lds, s);
+      case EPI_R2 | EPI_STATS: return big_launch_fold<U, EPI_R2 | EPI_STATS>(id, a, n_tiles, tiles_total, grid, lds, s);
+      case EPI_R1 | EPI_MASK | EPI_STATS: return big_launch_fold<U, EPI_R1 | EPI_MASK | EPI_STATS>(id, a, n_tiles, tiles_total, grid, lds, s);
       case 0: return big_launch_geometry<U, 0>(id, a, n_tiles, tiles_total, grid, lds, s);
       case EPI_GELU: return big_launch_geometry<U, EPI_GELU>(id, a, n_tiles, tiles_total, grid, lds, s);
       case EPI_R1: return big_launch_geometry<U, EPI_R1>(id, a, n_tiles, tiles_total, grid, lds, s);
@@ -765,18 +782,13 @@ static int row_panel_launch(const LinearArgs& a, const RowPanelFuse& f, hipStrea
   const int tiles_total = a.M / 96, want = (tiles_total + 7) & ~7;
   const dim3 grid(static_cast<unsigned>(want < 256 ? want : 256));
   const size_t lds = 2 * static_cast<size_t>(96 + 512) * ROW_BYTES + 2 * 96 * 8 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_big<U, E, 1, 8, 1, FUSE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  D3PM_LDS_ATTR((&gemm_mfma_big<U, E, 1, 8, 1, FUSE>), 160 * 1024);
   RowPanelArgs<U> rp{static_cast<const U*>(f.X2), static_cast<const U*>(f.lnw), static_cast<const U*>(f.lnb),
                      static_cast<const U*>(f.lnw2), static_cast<const U*>(f.lnb2), static_cast<const U*>(f.film),
                      static_cast<U*>(f.lny), static_cast<U*>(f.lny2), f.eps, static_cast<uint8_t*>(f.sx), static_cast<uint8_t*>(f.sx2)};
   gemm_mfma_big<U, E, 1, 8, 1, FUSE><<<grid, dim3(512), lds, s>>>(
       static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
-      static_cast<const U*>(a.R1), nullptr, a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, 1, tiles_total, nullptr, rp);
+      static_cast<const U*>(a.R1), nullptr, a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, 1, tiles_total, nullptr, rp, EpiFold{});
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;
 }

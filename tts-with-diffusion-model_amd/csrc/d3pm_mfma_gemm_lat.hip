@@ -60,10 +60,10 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
                                                             const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                             int mask_period, int M, int N, int K, int n_tiles,
                                                             const uint16_t* __restrict__ gelu_tab_g, LnProArgs<T> ln,
-                                                            const T* __restrict__ X2 = nullptr) {
+                                                            EpiFold ef, const T* __restrict__ X2 = nullptr) {
   using G = LatGeom<TM, TN>;
   static_assert(!LNPRO || (TM == 64 && TN == 64), "the LayerNorm prologue is written for the base geometry");
-  static_assert(!DUAL || (!LNPRO && EPI == EPI_R1 && TN == 64), "two products: whole tiles, K = 2 rounds, x' = (R1 + h) + y2");
+  static_assert(!DUAL || (!LNPRO && (EPI & ~EPI_STATS) == EPI_R1 && TN == 64), "two products: whole tiles, K = 2 rounds, x' = (R1 + h) + y2");
   static_assert(TM % 32 == 0 && TN % 64 == 0, "four waves as 2 x 2, column blocks regrouped in pairs");
   constexpr int XP = TM / 32, WP = TN / 32;       // DMA pieces (8 rows) per wave and sub-tile = MFMA row / column blocks per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
   // the epilogue's operands (bias, residuals, frame mask) are requested FIRST: they are older than every DMA piece, so the
   // counted waits below cover them, and they have landed long before the last MFMA instead of starting a new round trip there
   EpiPre<T, WP, XP> pre;
-  if constexpr (!DUAL) epilogue_prefetch<T, EPI, WP, XP>(pre, bias, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * (TM / 2), n0 + wn * (TN / 2), lane);
+  if constexpr (!DUAL) epilogue_prefetch<T, EPI, WP, XP>(pre, bias, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * (TM / 2), n0 + wn * (TN / 2), lane, &ef);
   [[maybe_unused]] Pack8<T> dual_r1;
   [[maybe_unused]] EpiPre<T, WP, XP> dual_pre;
   if constexpr (DUAL) {
@@ -238,10 +238,24 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) o.v[i] = static_cast<T>(rn<T>(static_cast<float>(r1.v[i]) + static_cast<float>(hh.v[i])) + static_cast<float>(yy.v[i]));
     *reinterpret_cast<Pack8<T>*>(Y + static_cast<size_t>(m0 + wm * (TM / 2) + (lane & 15)) * ldy + n0 + wn * (TN / 2) + epilogue_nq(lane)) = o;
+    if constexpr ((EPI & EPI_STATS) != 0) {      // the moments of the new rows, in the order every epilogue uses (d3pm_mfma_tile.h: emit_stats)
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(o.v[i]);
+      float a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      float q = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+      a = add_xor16(a); q = add_xor16(q);
+      a = add_xor32(a); q = add_xor32(q);
+      if (lane < 16) {
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        const size_t m = static_cast<size_t>(m0 + wm * (TM / 2) + lane);
+        *reinterpret_cast<float2v*>(ef.stats_out + (m * (N >> 5) + ((n0 + wn * (TN / 2)) >> 5)) * 2) = float2v{a, q};
+      }
+    }
     return;
   }
   epilogue_store<T, EPI, WP, XP, false, false, false, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * (TM / 2),
-                                                            n0 + wn * (TN / 2), lane, nullptr, gelu_tab, &pre);
+                                                            n0 + wn * (TN / 2), lane, nullptr, gelu_tab, &pre, &ef);
 }
 
 inline bool aligned16l(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
@@ -256,9 +270,9 @@ bool panel64_linear_supported(int dtype, const LinearArgs& a) {
   if (a.R2 && (!a.R1 || !aligned16l(a.R2))) return false;
   const bool gelu = a.act == ACT_GELU, r1 = a.R1 != nullptr, r2 = a.R2 != nullptr, mk = a.row_mask != nullptr;
   if (a.act != ACT_NONE && !gelu) return false;
-  if (gelu && (r1 || mk)) return false;       // instantiated epilogues: plain, GELU, R1, R1+R2, R1+mask
+  if (gelu && (r1 || mk)) return false;       // instantiated epilogues: plain, GELU, R1, R1+R2, R1+mask; LNF, LNF+GELU; R1 / R2 / R1+mask + STATS
   if (mk && (!r1 || r2)) return false;
-  return true;
+  return fold_args_ok(a);
 }
 
 #ifdef D3PM_ABLATIONS
@@ -297,18 +311,14 @@ static int panel64_launch(const LinearArgs& a, const LnPrologue* lnp, const uint
   if (2 * G::BUF + GELU_TAB_BYTES > 160 * 1024) tab = nullptr;            // no room for the table beside this geometry's panels
   const size_t lds = 2 * G::BUF + (tab ? GELU_TAB_BYTES : 0);
   const int n_tiles = (a.N + TN - 1) / TN, m_tiles = (a.M + TM - 1) / TM;
-  static bool attr_set = false;
-  if (!attr_set) {
-    D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_panel64<U, E, LN, TM, TN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-    attr_set = true;
-  }
+  D3PM_LDS_ATTR((&gemm_mfma_panel64<U, E, LN, TM, TN>), kMaxLds);
   LnProArgs<U> la{};
   if (lnp) la = LnProArgs<U>{static_cast<const U*>(lnp->w), static_cast<const U*>(lnp->b), static_cast<const U*>(lnp->w2),
                              static_cast<const U*>(lnp->b2), static_cast<const U*>(lnp->film), lnp->eps, lnp->period};
   gemm_mfma_panel64<U, E, LN, TM, TN><<<dim3(static_cast<unsigned>(n_tiles * m_tiles)), dim3(256), lds, s>>>(
       static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
-      static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles, tab, la);
+      static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles, tab, la,
+      epi_fold_of(a));
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;
 }
@@ -326,6 +336,7 @@ template <typename U, int E> static int panel64_geometry(const LinearArgs& a, co
 bool panel64_dual_supported(int dtype, const LinearArgs& a, const void* X2) {
   if (!panel64_linear_supported(dtype, a) || !X2 || !aligned16l(X2)) return false;
   if (a.K != 2 * KC || a.M % 32 != 0 || a.N % 64 != 0 || a.M > 2048) return false;
+  if (a.fold_s || a.M % 32 != 0) return false;
   return a.R1 && !a.R2 && !a.row_mask && a.act == ACT_NONE && a.bias;
 }
 
@@ -335,15 +346,19 @@ int panel64_dual(int dtype, const LinearArgs& a, const void* X2, hipStream_t s) 
   const int n_tiles = a.N / 64, m_tiles = a.M / 32;
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_panel64<U, EPI_R1, false, 32, 64, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      attr_set = true;
+    if (a.stats_out) {
+      D3PM_LDS_ATTR((&gemm_mfma_panel64<U, EPI_R1 | EPI_STATS, false, 32, 64, true>), lds);
+      gemm_mfma_panel64<U, EPI_R1 | EPI_STATS, false, 32, 64, true><<<dim3(static_cast<unsigned>(n_tiles * m_tiles)), dim3(256), lds, s>>>(
+          static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
+          static_cast<const U*>(a.R1), nullptr, a.ldr, nullptr, 1, a.M, a.N, a.K, n_tiles, nullptr, LnProArgs<U>{}, epi_fold_of(a),
+          static_cast<const U*>(X2));
+    } else {
+      D3PM_LDS_ATTR((&gemm_mfma_panel64<U, EPI_R1, false, 32, 64, true>), lds);
+      gemm_mfma_panel64<U, EPI_R1, false, 32, 64, true><<<dim3(static_cast<unsigned>(n_tiles * m_tiles)), dim3(256), lds, s>>>(
+          static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
+          static_cast<const U*>(a.R1), nullptr, a.ldr, nullptr, 1, a.M, a.N, a.K, n_tiles, nullptr, LnProArgs<U>{}, EpiFold{},
+          static_cast<const U*>(X2));
     }
-    gemm_mfma_panel64<U, EPI_R1, false, 32, 64, true><<<dim3(static_cast<unsigned>(n_tiles * m_tiles)), dim3(256), lds, s>>>(
-        static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
-        static_cast<const U*>(a.R1), nullptr, a.ldr, nullptr, 1, a.M, a.N, a.K, n_tiles, nullptr, LnProArgs<U>{}, static_cast<const U*>(X2));
     D3PM_LAUNCH_CHECK();
     return D3PM_OK;
   };
@@ -356,7 +371,8 @@ int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s, const LnProlog
 #else
   const uint16_t* tab = nullptr;
 #endif
-  const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
+  const int epi = (a.act == ACT_GELU ? EPI_GELU : 0) | (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0) |
+                  (a.fold_s ? EPI_LNF : 0) | (a.stats_out ? EPI_STATS : 0);
   auto go = [&](auto* tag) -> int {
     using U = std::remove_pointer_t<decltype(tag)>;
 #ifdef D3PM_ABLATIONS
@@ -376,6 +392,11 @@ int panel64_linear(int dtype, const LinearArgs& a, hipStream_t s, const LnProlog
       case EPI_R1: return panel64_geometry<U, EPI_R1>(a, tab, s);
       case EPI_R2: return panel64_geometry<U, EPI_R2>(a, tab, s);
       case EPI_R1 | EPI_MASK: return panel64_geometry<U, EPI_R1 | EPI_MASK>(a, tab, s);
+      case EPI_LNF: return panel64_geometry<U, EPI_LNF>(a, tab, s);
+      case EPI_LNF | EPI_GELU: return panel64_geometry<U, EPI_LNF | EPI_GELU>(a, tab, s);
+      case EPI_R1 | EPI_STATS: return panel64_geometry<U, EPI_R1 | EPI_STATS>(a, tab, s);
+      case EPI_R2 | EPI_STATS: return panel64_geometry<U, EPI_R2 | EPI_STATS>(a, tab, s);
+      case EPI_R1 | EPI_MASK | EPI_STATS: return panel64_geometry<U, EPI_R1 | EPI_MASK | EPI_STATS>(a, tab, s);
       default: break;
     }
     return D3PM_E_SHAPE;

@@ -165,12 +165,7 @@ int ring_linear(int dtype, const LinearArgs& a, hipStream_t s) {
   const int epi = (a.R1 ? (a.R2 ? EPI_R2 : EPI_R1) : 0) | (a.row_mask ? EPI_MASK : 0);
 #define D3PM_RING(E)                                                                                                     \
   do {                                                                                                                   \
-    static bool attr_set = false;                                                                                        \
-    if (!attr_set) {                                                                                                     \
-      D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_ring<U, E>),                           \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT));                     \
-      attr_set = true;                                                                                                   \
-    }                                                                                                                    \
+    D3PM_LDS_ATTR((&gemm_mfma_ring<U, E>), NSLOT * SLOT);                                                                \
     gemm_mfma_ring<U, E><<<grid, block, lds, s>>>(static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W),          \
         static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy, static_cast<const U*>(a.R1), static_cast<const U*>(a.R2), \
         a.ldr, a.row_mask, a.mask_period, a.M, a.N, a.K, n_tiles, tiles_total);                                          \

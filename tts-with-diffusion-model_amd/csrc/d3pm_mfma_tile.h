@@ -87,7 +87,59 @@ __device__ __forceinline__ void gelu_table_to_lds(const uint16_t* __restrict__ g
 // directly by an MFMA.
 // Residual loads are branch-free (clamped addresses) and batched per row; only the stores are predicated.
 // EPI bits: 1 = exact-erf GELU, 2 = one residual (R1), 4 = two residuals (R1, R2), 8 = frame mask, 16 = ReLU, 32 = SiLU
-constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8, EPI_RELU = 16, EPI_SILU = 32;
+//           64 = LayerNorm folded into this projection (EPI_LNF), 128 = row moments of the output rows (EPI_STATS): below
+constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8, EPI_RELU = 16, EPI_SILU = 32, EPI_LNF = 64, EPI_STATS = 128;
+
+// LayerNorm taken out of the launch list algebraically (ar_discrete.py:131-132, 136-142, 153-159: LayerNorm -> Linear).  With
+// W' = W o gamma (rounded to the storage type once, at weight-preparation time), s_n = sum_k W'[n][k] and
+// b'_n = sum_k W[n][k] beta_k + b_n,
+//     LN(x) W^T + b  =  rstd_r (x_r . W'^T  -  mean_r s)  +  b'
+// so the projection that CONSUMES a LayerNorm reads the raw residual stream through the unchanged operand path and applies two
+// per-row scalars and two per-column vectors in its epilogue (EPI_LNF), and the projection that PRODUCES the residual rows
+// (out-projection / fc2 + residual) leaves their moments behind (EPI_STATS): per row and per 32-column part of the row the pair
+// (sum y, sum y^2) of the ROUNDED values it stores, fp32, no atomics -- stats[M][N / 32][2].  A part is what one 16-lane row group
+// of any MFMA kernel's epilogue owns after the column regrouping (8 columns in each of 4 lanes), so every tile geometry sums a
+// part in the same order and writes the same bits; the consumer adds a row's parts in one fixed order (four lanes x parts_in / 4
+// parts each, then two butterfly steps).  var = E[y^2] - mean^2 in fp32: with |mean| <~ 10 sigma the relative error of rstd stays
+// below 1e-5, two orders under the 16-bit storage quantum.  This skips the 16-bit rounding of the LayerNorm output (closer to the
+// fp32 model than the eager chain); the F32 / generic family keeps the stand-alone LayerNorm.
+struct EpiFold {
+  const float* s = nullptr;          // [N]  sum_k W'[n][k]
+  const float* b = nullptr;          // [N]  folded bias b'
+  const float* stats_in = nullptr;   // [M][parts_in][2]  moments of the operand rows (the residual stream, K columns)
+  float* stats_out = nullptr;        // [M][N / 32][2]    moments of the rows this launch stores (N = d_model)
+  float eps = 1e-6f;
+  int parts_in = 0;                  // K / 32, a multiple of 8
+};
+
+inline EpiFold epi_fold_of(const LinearArgs& a) {
+  EpiFold e;
+  e.s = a.fold_s; e.b = a.fold_b; e.stats_in = a.stats_in; e.stats_out = a.stats_out; e.eps = a.fold_eps; e.parts_in = a.K / 32;
+  return e;
+}
+
+// (sum, sum of squares) of row `row` from its parts: lane group g = lane >> 4 adds parts [g P / 4, (g + 1) P / 4) in order, then the
+// four groups are combined by two butterfly steps (a + b == b + a bit for bit, so all four lanes end with the same bits)
+__device__ __forceinline__ void fold_row_moments(const float* __restrict__ stats, int parts, size_t row, int g, float& s1, float& s2) {
+  const int per = parts >> 2;
+  const floatx4* p = reinterpret_cast<const floatx4*>(stats + (row * parts + static_cast<size_t>(g) * per) * 2);
+  float a = 0.f, q = 0.f;
+  for (int i = 0; i < (per >> 1); ++i) {
+    const floatx4 v = p[i];
+    a += v[0]; q += v[1];
+    a += v[2]; q += v[3];
+  }
+  a = add_xor16(a); q = add_xor16(q);
+  s1 = add_xor32(a); s2 = add_xor32(q);
+}
+// the two per-row scalars of EPI_LNF: y = fma(acc, ra, fma(rc, s_n, b'_n)) with ra = rstd, rc = -mean rstd
+__device__ __forceinline__ void fold_row_scalars(float s1, float s2, int d, float eps, float& ra, float& rc) {
+  const float inv_d = 1.0f / static_cast<float>(d);
+  const float mean = s1 * inv_d;
+  const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv_d), 0.f);
+  ra = rsqrtf(var + eps);
+  rc = -mean * ra;
+}
 
 typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
 template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
@@ -113,15 +165,36 @@ template <typename T, int NT, int MT> struct EpiPre {
   float bv[NT][4];
   Pack8<T> r1[MT][NT / 2], r2[MT][NT / 2];
   float mk[MT];
+  float sv[NT][4];             // EPI_LNF: s_n beside b'_n (bv)
+  floatx4 st[MT][2];           // EPI_LNF, parts_in == 16 (d_model = 512): the lane's four parts of each of its rows, not yet reduced
 };
 template <typename T, int EPI, int NT, int MT>
 __device__ __forceinline__ void epilogue_prefetch(EpiPre<T, NT, MT>& pre, const T* __restrict__ bias, const T* R1, const T* R2, int ldr,
                                                   const uint8_t* __restrict__ row_mask, int mask_period, int M, int N, int mw0,
-                                                  int nw0, int lane) {
+                                                  int nw0, int lane, const EpiFold* ef = nullptr) {
   constexpr bool kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
+  constexpr bool kLnf = (EPI & EPI_LNF) != 0;
   constexpr int NP = NT / 2;
   const int g = lane >> 4, nq = (g & 1) * 16 + (g >> 1) * 8;
-  if (bias == nullptr) {
+  if constexpr (kLnf) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      int n = nw0 + nt * 16 + g * 4;
+      n = n < N ? n : N - 4;
+      const floatx4 b4 = *reinterpret_cast<const floatx4*>(ef->b + n), s4 = *reinterpret_cast<const floatx4*>(ef->s + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pre.bv[nt][r] = b4[r]; pre.sv[nt][r] = s4[r]; }
+    }
+    if (ef->parts_in == 16) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mw0 + mt * 16 + (lane & 15);
+        const floatx4* p = reinterpret_cast<const floatx4*>(ef->stats_in + (static_cast<size_t>(m < M ? m : M - 1) * 16 + g * 4) * 2);
+        pre.st[mt][0] = p[0];
+        pre.st[mt][1] = p[1];
+      }
+    }
+  } else if (bias == nullptr) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -175,17 +248,58 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
                                                const T* R1, const T* R2, int ldr, const uint8_t* __restrict__ row_mask,
                                                int mask_period, int M, int N, int mw0, int nw0, int lane,
                                                uintx4* packed = nullptr, const uint16_t* gelu_tab = nullptr,
-                                               const EpiPre<T, NT, MT>* pre = nullptr) {   // pre: read only when kPre
+                                               const EpiPre<T, NT, MT>* pre = nullptr,      // pre: read only when kPre
+                                               const EpiFold* ef = nullptr) {               // ef: read only under EPI_LNF / EPI_STATS
   static_assert(!kPack || kInteriorOnly, "packing to registers is for whole tiles");
   static_assert(NT % 2 == 0, "column blocks are regrouped in pairs");
   constexpr bool kGelu = EPI & EPI_GELU, kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
+  constexpr bool kLnf = (EPI & EPI_LNF) != 0, kStats = (EPI & EPI_STATS) != 0;
+  static_assert(!(kLnf && (kR1 || kMask)) && !(kStats && kPack), "instantiated: LNF [+ GELU]; R1 / R2 / R1 + mask [+ STATS]");
   constexpr int NP = NT / 2;
   const int g = lane >> 4;
   const int nq = (g & 1) * 16 + (g >> 1) * 8;           // column of this lane's 8-group inside a 32-column pair
   // bias in the MFMA layout (applied before the regrouping).  Loads are branch-free per lane -- clamped addresses,
   // one batch, one wait: per-element predicated loads compile to sixteen serialized L2 round trips.
   float bv[NT][4];
-  if constexpr (kPre) {
+  [[maybe_unused]] float sv[NT][4], ra[MT], rc[MT];
+  if constexpr (kLnf) {
+    // per-column vectors b'_n, s_n (fp32) and the two per-row scalars from the producer's partial moments
+    if constexpr (kPre) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bv[nt][r] = pre->bv[nt][r]; sv[nt][r] = pre->sv[nt][r]; }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        int n = nw0 + nt * 16 + g * 4;
+        n = n < N ? n : N - 4;
+        const floatx4 b4 = *reinterpret_cast<const floatx4*>(ef->b + n), s4 = *reinterpret_cast<const floatx4*>(ef->s + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bv[nt][r] = b4[r]; sv[nt][r] = s4[r]; }
+      }
+    }
+    const int d_in = ef->parts_in * 32;
+    if (kPre && ef->parts_in == 16) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const floatx4 p0 = pre->st[mt][0], p1 = pre->st[mt][1];
+        float a = 0.f, q = 0.f;
+        a += p0[0]; q += p0[1]; a += p0[2]; q += p0[3];
+        a += p1[0]; q += p1[1]; a += p1[2]; q += p1[3];
+        a = add_xor16(a); q = add_xor16(q);
+        fold_row_scalars(add_xor32(a), add_xor32(q), d_in, ef->eps, ra[mt], rc[mt]);
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mw0 + mt * 16 + (lane & 15);
+        float s1, s2;
+        fold_row_moments(ef->stats_in, ef->parts_in, static_cast<size_t>(m < M ? m : M - 1), g, s1, s2);
+        fold_row_scalars(s1, s2, d_in, ef->eps, ra[mt], rc[mt]);
+      }
+    }
+  } else if constexpr (kPre) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -223,7 +337,10 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
   auto finish = [&](float (&v)[8], int np, int mt) {   // bias + activation in the MFMA layout, then the regrouping
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      v[r] = rn<T>(acc[2 * np + (r >> 2)][mt][r & 3] + bv[2 * np + (r >> 2)][r & 3]);
+      if constexpr (kLnf)
+        v[r] = rn<T>(__builtin_fmaf(acc[2 * np + (r >> 2)][mt][r & 3], ra[mt], __builtin_fmaf(rc[mt], sv[2 * np + (r >> 2)][r & 3], bv[2 * np + (r >> 2)][r & 3])));
+      else
+        v[r] = rn<T>(acc[2 * np + (r >> 2)][mt][r & 3] + bv[2 * np + (r >> 2)][r & 3]);
       if constexpr (kGelu) {
         if constexpr (std::is_same<T, bf16>::value) v[r] = gelu_tab ? gelu_bf16_lookup(v[r], gelu_tab) : rn<T>(gelu_erf(v[r]));
         else v[r] = rn<T>(gelu_erf(v[r]));
@@ -233,6 +350,18 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) swap_rows16(v[r], v[4 + r]);
+  };
+  // EPI_STATS: (sum, sum of squares) of the 32 stored values of row m in column part (nw0 + 32 np) / 32 -- eight in this lane, the
+  // other 24 in the lanes 16 / 32 / 48 away; the order below is the definition of a part's moments for every kernel
+  auto emit_stats = [&](const float (&v)[8], int m, int np, bool ok) {
+    float a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    float q = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+    a = add_xor16(a); q = add_xor16(q);
+    a = add_xor32(a); q = add_xor32(q);
+    if (g == 0 && ok) {
+      typedef float float2v __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<float2v*>(ef->stats_out + (static_cast<size_t>(m) * (N >> 5) + ((nw0 + np * 32) >> 5)) * 2) = float2v{a, q};
+    }
   };
   if (kInteriorOnly || (mw0 + MT * 16 <= M && nw0 + NT * 16 <= N)) {
     // interior wave tile (wave-uniform test): no clamps or predicates, one 64-bit row pointer per operand that
@@ -272,6 +401,7 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
           }
           if (kMask) v[r] *= mk;
         }
+        if constexpr (kStats) emit_stats(v, m + mt * 16, np, true);
         const uintx4 grp = uintx4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
         if constexpr (kPack) packed[mt * NP + np] = grp;
         else if constexpr (kNts) __builtin_nontemporal_store(grp, reinterpret_cast<uintx4*>(y + np * 32));   // streaming output: do not keep it in L2
@@ -319,6 +449,11 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
           if (kR2) res = rn<T>(res + static_cast<float>(p2[np].v[r]));
           v[r] = rn<T>(res + v[r]);
         }
+      }
+      if constexpr (kStats) {          // N is a multiple of 32 (launcher): a part is stored whole or not at all
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= mk;
+        emit_stats(v, mc, np, m < M && nw0 + np * 32 < N);
       }
       if (m < M && n < N) {
         T* y = Y + static_cast<size_t>(m) * ldy + n;

@@ -403,12 +403,7 @@ static int mx_launch(const MxLinearArgs& a, hipStream_t s) {
   const int slots = 256 * (8 / NWAVE), want = (tiles_total + 7) & ~7;
   const dim3 grid(static_cast<unsigned>(want < slots ? want : slots));
   const size_t lds = 2 * static_cast<size_t>(TM + TN) * ROW_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    D3PM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_big<U, E, WM, WN, OUT8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  D3PM_LDS_ATTR((&gemm_mx_big<U, E, WM, WN, OUT8>), 160 * 1024);
   gemm_mx_big<U, E, WM, WN, OUT8><<<grid, dim3(NWAVE * 64), lds, s>>>(
       static_cast<const uint8_t*>(a.X8), a.ldx, static_cast<const uint8_t*>(a.SX), static_cast<const uint8_t*>(a.W8),
       static_cast<const uint8_t*>(a.SW), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy, static_cast<const U*>(a.R1), a.ldr,

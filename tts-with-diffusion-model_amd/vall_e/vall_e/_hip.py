@@ -6,6 +6,7 @@ PyTorch is used only to own device memory and to provide the current HIP stream.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 
@@ -13,7 +14,7 @@ import numpy as np
 import torch
 
 F32, F16, BF16 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 FLAG_GREEDY, FLAG_FORCE_GENERIC, FLAG_SEED_IN_HBM = 1, 2, 4
 K_GEMM, K_ATTN, K_SAMPLE, K_LN, K_GEMM_LN, K_ALL = 0, 1, 2, 3, 4, 5
 
@@ -27,7 +28,8 @@ class Tuning(C.Structure):
     """d3pm_tuning (include/d3pm_hip.h): schedule choices, every value bit-identical.  The C library keeps no state: a
     pointer to one of these travels in the shape structs.  `TUNING` below is this module's default instance."""
     _fields_ = [(n, C.c_int32) for n in ("gemm_variant", "gemm_persist_slots", "lat_tile", "attn_query_groups",
-                                         "attn_pair_sequential", "attn_cross_resident", "row_panel", "workspace_alias")] + \
+                                         "attn_pair_sequential", "attn_cross_resident", "row_panel", "workspace_alias",
+                                         "regime_batch", "ln_fold")] + \
                [("prof", C.c_void_p)]
 
 
@@ -45,9 +47,14 @@ class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _BLOCK_FIELDS]
 
 
+class FoldBlock(C.Structure):
+    """d3pm_fold_block: a block's LayerNorms folded into the projections they feed (filled by d3pm_fold_build)."""
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "qkv_s", "qkv_b", "q2_w", "q2_s", "q2_b", "fc1_w", "fc1_s", "fc1_b")]
+
+
 class Weights(C.Structure):
     _fields_ = [("resps_emb", C.c_void_p), ("time_emb", C.c_void_p), ("final_w", C.c_void_p),
-                ("final_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights))]
+                ("final_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights)), ("fold", C.POINTER(FoldBlock))]
 
 
 _ENC_LAYER_FIELDS = ("in_w", "in_b", "out_w", "out_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b", "norm1_w", "norm1_b",
@@ -103,6 +110,16 @@ SIGNATURES = {
     "d3pm_schedule_build": (C.c_int, [C.c_int] + [C.POINTER(C.c_uint16)] * 5),
     "d3pm_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int]),
     "d3pm_film_table": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_void_p, C.c_void_p]),
+    "d3pm_fold_bytes": (C.c_size_t, [C.POINTER(Shape)]),
+    "d3pm_fold_build": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FoldBlock),
+                                  C.c_void_p]),
+    "d3pm_op_row_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "d3pm_op_linear_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Tuning), C.c_void_p]),
+    "d3pm_op_linear_fold": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Tuning), C.c_void_p]),
+    "d3pm_op_fold_weights": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "d3pm_cond_kv": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_int] + [C.c_void_p] * 5),
     "d3pm_cond_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(CondWeights), C.c_int]),
     "d3pm_encode_conditions": (C.c_int, [C.POINTER(Shape), C.POINTER(CondWeights), C.c_int, C.c_void_p, C.c_void_p,
@@ -190,6 +207,7 @@ AB_SIGNATURES = {
 AB_GEMM_BIG_MODE, AB_ATTN_ARM, AB_GEMM_RING, AB_GELU_TABLE, AB_LN_PROLOGUE, AB_FUSED_FINAL_SAMPLE = range(6)
 _is_ab = False
 TUNING = Tuning()        # filled by d3pm_tuning_default when the library loads
+TUNING_FIELDS = tuple(n for n, _ in Tuning._fields_ if n != "prof")
 
 
 def _load(path, signatures):
@@ -299,7 +317,22 @@ class DeviceWeights:
             for field, key in names.items():
                 setattr(self.blocks[i], field, ptr(f"blocks.{i}.{key}"))
         self.c_struct = Weights(ptr("resps_emb.weight"), ptr("time_emb.weight"), ptr("final.weight"),
-                                ptr("final.bias"), self.blocks)
+                                ptr("final.bias"), self.blocks, None)
+        self.fold_blocks = self.fold_storage = None
+
+    def build_fold(self, shape: "Shape", film: torch.Tensor, device):
+        """The LayerNorm-folded projection tables (d3pm_fold_build): W o gamma per LayerNorm-fed projection, one fc1 copy per
+        (layer, timestep) for the FiLM modulation -- (timesteps + 1) x n_layers x 4 d^2 elements, 1.27 GB for the 100-step d = 512
+        model -- plus the fp32 column vectors.  Shapes that do not qualify (fp32, d_model not a multiple of 256) keep fold = NULL."""
+        need = lib().d3pm_fold_bytes(C.byref(shape))
+        if need == 0:
+            return False
+        self.fold_storage = torch.empty(need, dtype=torch.uint8, device=device)
+        self.fold_blocks = (FoldBlock * shape.n_layers)()
+        check(lib().d3pm_fold_build(C.byref(shape), C.byref(self.c_struct), _p(film), _p(self.fold_storage), need, self.fold_blocks,
+                                    stream_ptr()), "d3pm_fold_build")
+        self.c_struct.fold = self.fold_blocks
+        return True
 
 
 class Fp8BlockWeights(C.Structure):
@@ -403,6 +436,8 @@ class Sampler:
         self.film = torch.empty((cfg.timesteps + 1, cfg.n_layers, 2 * cfg.d_model), dtype=dtype, device=self.device)
         check(lib().d3pm_film_table(C.byref(self.shape), C.byref(self.weights.c_struct), _p(self.film), stream_ptr()),
               "d3pm_film_table")
+        # LayerNorm folded into the projections (include/d3pm_hip.h: d3pm_fold_block; tuning field ln_fold picks it per call)
+        self.folded = self.weights.build_fold(self.shape, self.film, self.device)
 
     def fp8_weights(self) -> DeviceFp8Weights:
         """e4m3 weight copies for the fp8 fast path, quantised on first use."""
@@ -714,6 +749,46 @@ def op_attention_pair(q1, k1, v1, q2, k2, v2, n_heads, scale):
     return o1, o2
 
 
+def op_row_stats(x):
+    """[M, d] 16-bit rows -> fp32 [M, d // 32, 2] partial (sum, sum of squares) per 32-column part."""
+    M, d = x.shape
+    st = torch.empty((M, d // 32, 2), dtype=torch.float32, device=x.device)
+    check(lib().d3pm_op_row_stats(dtype_code(x.dtype), _p(x), x.stride(0), M, d, _p(st), stream_ptr()), "d3pm_op_row_stats")
+    return st
+
+
+def op_linear_stats(x, w, bias, r1, *, r2=None, row_mask=None, mask_period=1):
+    """(y, stats): y = residual epilogue of d3pm_op_linear, stats = the moments of the rows of y ([M, N // 32, 2])."""
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    st = torch.empty((M, N // 32, 2), dtype=torch.float32, device=x.device)
+    check(lib().d3pm_op_linear_stats(dtype_code(x.dtype), _p(x), x.stride(0), _p(w), _p(bias), _p(y), N, _p(r1), _p(r2), r1.stride(0),
+                                     _p(row_mask), mask_period, M, N, K, _p(st), C.byref(TUNING), stream_ptr()), "d3pm_op_linear_stats")
+    return y, st
+
+
+def op_fold_weights(w, bias, gamma, beta, film=None):
+    """(Wf [N, K] in w's dtype, fold_s [N] fp32, fold_b [N] fp32) of one LayerNorm-fed projection (d3pm_op_fold_weights)."""
+    N, K = w.shape
+    wf = torch.empty_like(w)
+    fs = torch.empty(N, dtype=torch.float32, device=w.device)
+    fb = torch.empty(N, dtype=torch.float32, device=w.device)
+    check(lib().d3pm_op_fold_weights(dtype_code(w.dtype), _p(w), _p(bias), _p(gamma), _p(beta), _p(film), N, K, _p(wf), _p(fs), _p(fb),
+                                     stream_ptr()), "d3pm_op_fold_weights")
+    return wf, fs, fb
+
+
+def op_linear_fold(x, wf, fold_s, fold_b, stats, *, act=0, eps=1e-6):
+    """act(LN-folded projection) of the raw rows x [M, K] with their moments `stats` (d3pm_op_linear_fold)."""
+    M, K = x.shape
+    N = wf.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(lib().d3pm_op_linear_fold(dtype_code(x.dtype), _p(x), x.stride(0), _p(wf), _p(fold_s), _p(fold_b), _p(stats), eps, _p(y), N,
+                                    M, N, K, act, C.byref(TUNING), stream_ptr()), "d3pm_op_linear_fold")
+    return y
+
+
 def op_layernorm(x, w, b, film=None, eps=1e-6):
     y = torch.empty_like(x)
     check(lib().d3pm_op_layernorm(dtype_code(x.dtype), _p(x), _p(y), _p(w), _p(b), _p(film), x.shape[0], x.shape[1],
@@ -861,14 +936,30 @@ def set_workspace_alias(v: bool):
     TUNING.workspace_alias = 1 if v else 0
 
 
+@contextlib.contextmanager
+def tuning(**fields):
+    """`with _hip.tuning(attn_query_groups=32, row_panel=0): ...` -- schedule choices for the calls made inside the block; the
+    module's default Tuning is restored on exit, also when the body raises, so no test or caller can leak a schedule."""
+    lib()
+    for name in fields:
+        if name not in TUNING_FIELDS:
+            raise D3PMError(f"unknown tuning field {name!r}: one of {TUNING_FIELDS}")
+    saved = {name: getattr(TUNING, name) for name in fields}
+    try:
+        for name, value in fields.items():
+            setattr(TUNING, name, int(value))
+        yield TUNING
+    finally:
+        for name, value in saved.items():
+            setattr(TUNING, name, value)
+
+
 def reset_tuning():
     """Back to the library's defaults (d3pm_tuning_default); an attached profiler stays attached."""
     prof = TUNING.prof
     lib().d3pm_tuning_default(C.byref(TUNING))
     TUNING.prof = prof
 
-
-TUNING_FIELDS = tuple(n for n, _ in Tuning._fields_ if n != "prof")
 
 
 def set_tuning_field(name: str, value: int):
@@ -957,3 +1048,8 @@ def prof_disable():
 
 def profiling() -> bool:
     return bool(TUNING.prof)
+
+
+import atexit  # noqa: E402
+
+atexit.register(lambda: prof_disable() if _lib is not None else None)      # a process that exits with a profiler attached frees its events

@@ -266,7 +266,7 @@ class AR(SymmapState, nn.Module):
     def generate_audio(self, text_list, proms_list, resps_list=None, *, steps: Optional[int] = None,
                        n_frames: Optional[int] = None, seed: Optional[int] = None, greedy: bool = False,
                        utt0: int = 0, return_trace: bool = False, flags: int = 0, streams: Optional[int] = None,
-                       graph: Optional[bool] = None, fp8: bool = False):
+                       graph: Optional[bool] = None, fp8: bool = False, global_batch: Optional[int] = None):
         """Reverse diffusion for len(text_list) utterances.  Positional behaviour as upstream:
         one utterance -> int64 [canvas] (squeezed, untrimmed; rows >= n_frames are sampled from
         final.bias and meaningless); with n_q > 1 (constructor) [canvas, n_q] / [B, canvas, n_q].  `resps_list` is ignored, as
@@ -274,6 +274,10 @@ class AR(SymmapState, nn.Module):
         `fp8=True` is the fast configuration of BASELINE.json configs[4]: the QKV, cross-attention query, fc1 and fc2
         projections run on the block-scaled fp8 matrix instruction (e4m3 codes, one power-of-two scale per 32 elements;
         d_model = 512, 16-bit model, batch * canvas a multiple of 192); the reference has no such mode.
+        `global_batch`: the size of the logical batch these utterances are a shard of (vall_e/vall_e/dp.py passes it; the stream
+        chunks below do too).  The attention kernels come in two instruction shapes that are picked by batch size and accumulate
+        in different orders; with the global batch given, a shard takes the kernels of the unsplit batch, so the ids of an
+        utterance do not depend on how the batch was split (d3pm_tuning.regime_batch).
         `graph=True` replays the loop from a captured HIP graph (seed read from HBM, identical results).  Off by
         default: measured on MI355X one utterance takes 66.6 ms replayed and 66.3 ms launched eagerly -- the ~5000
         kernels of a reverse process are bound by their own ~10 us latency at M = 768 rows, not by launch overhead."""
@@ -287,7 +291,8 @@ class AR(SymmapState, nn.Module):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # follows torch.manual_seed
         n_streams = max(1, min(B, self.loop_streams if streams is None else streams))
-        with torch.cuda.device(self.device):
+        regime = max(int(global_batch), B) if global_batch else (B if n_streams > 1 else 0)
+        with torch.cuda.device(self.device), _hip.tuning(regime_batch=regime):
             cond_text, cond_prompt = self.encode_conditions(text_list, proms_list)
             x, frame_mask = self.canvas_init(B, n_frames)
             fl = flags | (_hip.FLAG_GREEDY if greedy else 0)

@@ -3,7 +3,10 @@
 Utterances are independent (weights replicated, one Philox row block per *global* utterance index),
 so the batch is split contiguously over ranks with no data-path collective; the only exchange is one
 all-gather of the generated int32 token grid at the end (RCCL over xGMI when the backend is "nccl";
-gloo in the CPU tests).  Results are independent of the number of ranks by construction.
+gloo in the CPU tests).  Results are independent of the number of ranks: the noise rows are keyed by the global utterance
+index, every GEMM schedule is bit-compatible with every other, and the one choice that is not -- the instruction shape of the
+attention kernels, picked by batch size -- is made for the GLOBAL batch on every rank (`global_batch=`, d3pm_tuning.regime_batch).
+tests/test_gpu_batch_sweep.py holds a shard against the unsplit batch bit for bit.
 The reference has no multi-GPU inference (its only distributed code is DeepSpeed DP training,
 /root/reference/vall_e/train.py:29-31); this module is new in the build.
 """
@@ -31,6 +34,8 @@ def generate_audio_dp(model, text_list: Sequence[torch.Tensor], proms_list: Sequ
     B = len(text_list)
     lo, hi = shard_bounds(B, world, rank)
     fn = generate_fn or model.generate_audio
+    if generate_fn is None:
+        kw = dict(kw, global_batch=B)          # a shard takes the attention kernels of the unsplit batch: same ids at any rank count
     if hi > lo:
         local = fn(list(text_list[lo:hi]), list(proms_list[lo:hi]), seed=seed, utt0=lo, **kw)
         local = local.reshape(hi - lo, -1).to(torch.int32)
@@ -69,6 +74,8 @@ def generate_codes_dp(ar, nar, text_list: Sequence[torch.Tensor], proms_list: Se
     n_frames, levels = ar.cfg.n_frames, nar.n_resp_levels + 1
     gen = ar_fn or ar.generate_audio
     fill = nar_fn or nar
+    if ar_fn is None:
+        kw = dict(kw, global_batch=B)
     local = None
     if hi > lo:
         texts, proms = list(text_list[lo:hi]), list(proms_list[lo:hi])
