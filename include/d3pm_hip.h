@@ -130,8 +130,8 @@ enum {
  *   ln_fold            1 (default) = when d3pm_weights.fold is given, the LayerNorm-fed projections (norm1 -> QKV, norm2 | norm22 ->
  *                      cross-attention queries, norm3 + FiLM -> fc1) read the raw residual stream and apply the LayerNorm in their
  *                      epilogue from row moments the producing projection left behind (d3pm_fold_block): no LayerNorm launch and
- *                      no row-panel launch in a block; 0 = the stand-alone / row-panel LayerNorm launches (the eager rounding
- *                      points).  Ignored (= 0) for fp32 models, D3PM_FLAG_FORCE_GENERIC and the fp8 entry points.
+ *                      no row-panel launch in a block (one small launch per evaluation rebuilds fc1's FiLM-folded weights for
+ *                      the timestep); 0 = the stand-alone / row-panel LayerNorm launches (the eager rounding points).  Ignored (= 0) for fp32 models, D3PM_FLAG_FORCE_GENERIC and the fp8 entry points.
  *   prof               optional timing hooks (d3pm_prof_create below), NULL = none. */
 struct d3pm_prof;
 typedef struct d3pm_tuning {
@@ -182,14 +182,14 @@ typedef struct d3pm_block_weights {
 } d3pm_block_weights;
 
 /* A block's LayerNorms folded into the projections they feed (ar_discrete.py:131-132, 136-142, 145-159), built by
- * d3pm_fold_build from d3pm_block_weights + the FiLM table; device pointers into the caller's `storage`.  For a projection
+ * d3pm_fold_build from d3pm_block_weights; device pointers into the caller's `storage`.  For a projection
  * y = LN(x) W^T + b:  w = rn(W o gamma) in the model dtype,  s[n] = sum_k w[n][k] and b[n] = sum_k W[n][k] beta[k] + b[n] in fp32, so
- * that y = rstd_r (x_r . w^T - mean_r s) + b.  fc1 carries FiLM (gamma_k rn(1 + scale_t[k]), beta_k rn(1 + scale_t[k]) + shift_t[k]):
- * one set per timestep. */
+ * that y = rstd_r (x_r . w^T - mean_r s) + b.  fc1 carries FiLM (gamma_k rn(1 + scale_t[k]), beta_k rn(1 + scale_t[k]) + shift_t[k]),
+ * which depends on the timestep: its folded copy is rebuilt for t at the top of every denoiser evaluation, into the workspace
+ * (one launch for all layers), and is not part of this struct. */
 typedef struct d3pm_fold_block {
   const void *qkv_w;  const float *qkv_s, *qkv_b;     /* [3d][d]; [3d]                 norm1 -> attn in-projection                 */
   const void *q2_w;   const float *q2_s, *q2_b;       /* [2d][d]; [2d]                 norm2 -> q rows | norm22 -> the same q rows  */
-  const void *fc1_w;  const float *fc1_s, *fc1_b;     /* [timesteps+1][4d][d]; [timesteps+1][4d]   norm3 + FiLM(t) -> mlp.fc1       */
 } d3pm_fold_block;
 
 typedef struct d3pm_weights {
@@ -242,11 +242,11 @@ int d3pm_film_table(const d3pm_shape *shape, const d3pm_weights *w, void *film /
                     void *stream);
 
 /* LayerNorm folded into the projections: bytes of device storage for the tables of `shape` (0 when the shape does not qualify:
- * 16-bit dtype and d_model a multiple of 256), and the build -- `film` is the table d3pm_film_table wrote; blocks_out is a HOST
- * array of n_layers entries that receives pointers into `storage` (pass it as d3pm_weights.fold).  Once per weight set. */
+ * 16-bit dtype and d_model a multiple of 256), and the build; blocks_out is a HOST array of n_layers entries that receives
+ * pointers into `storage` (pass it as d3pm_weights.fold).  Once per weight set; 5 d^2 elements + 10 d floats per layer. */
 size_t d3pm_fold_bytes(const d3pm_shape *shape);
-int d3pm_fold_build(const d3pm_shape *shape, const d3pm_weights *w, const void *film /*device*/, void *storage /*device*/,
-                    size_t storage_bytes, d3pm_fold_block *blocks_out /*host*/, void *stream);
+int d3pm_fold_build(const d3pm_shape *shape, const d3pm_weights *w, void *storage /*device*/, size_t storage_bytes,
+                    d3pm_fold_block *blocks_out /*host*/, void *stream);
 
 /* K/V projections of the step-invariant conditions with cross_attn's k/v rows
  * (the `k`/`v` halves of F.multi_head_attention_forward's in-projection for the calls at

@@ -7,6 +7,17 @@ for st in $STAGES; do
   [ $ok -eq 1 ] || break
   case $st in
     kernels) timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -p no:cacheprovider -x > gpurun_out/pytest_kernels.log 2>&1; rc=$?; tail -15 gpurun_out/pytest_kernels.log;;
+    fold)    timeout -k 10 900 python -m pytest tests/test_gpu_fold.py tests/test_gpu_batch_sweep.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_fold.log 2>&1; rc=$?; tail -40 gpurun_out/pytest_fold.log;;
+    all)     timeout -k 10 1150 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_all.log 2>&1; rc=$?; tail -40 gpurun_out/pytest_all.log;;
+    benchq)  timeout -k 10 600 python bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-nar --no-nq8 --no-fp8 2> gpurun_out/benchq.err | tee gpurun_out/benchq.json; rc=${PIPESTATUS[0]}; tail -5 gpurun_out/benchq.err;;
+    profab)  cd /tmp && export TMPDIR=/tmp; rc=0
+             for arm in ${PROF_ARMS:-ln_fold=1 ln_fold=0}; do
+               tag=$(echo "$arm" | tr ',=' '__')
+               timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-steps 0 --no-latency --no-nar --no-nq8 --no-fp8 --no-kernel-events --profile-iters 24 --tune "$arm" ${PROF_EXTRA:-} > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1 || rc=$?
+               f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
+               echo "== $arm"; python3 $GRAFT_REPO_ROOT/tools/show_kernel_stats.py "$f" 22
+               cp "$f" $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_$tag.csv
+             done; cd $GRAFT_REPO_ROOT;;
     parity)  timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_parity.log 2>&1; rc=$?; tail -25 gpurun_out/pytest_parity.log;;
     nar)     timeout -k 10 600 python -m pytest tests/test_gpu_nar.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_nar.log 2>&1; rc=$?; tail -25 gpurun_out/pytest_nar.log;;
     smoke)   timeout -k 10 180 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; rc=$?; tail -3 gpurun_out/smoke.log;;

@@ -48,17 +48,15 @@ def _default_tuning():
 def gemm_variant(request, built_lib):
     """Every shipped schedule of the MFMA GEMM must pass the same numerics (auto selection is restored afterwards)."""
     from vall_e.vall_e import _hip
-    _hip.set_gemm_variant(request.param)
-    yield request.param
-    _hip.set_gemm_variant(0)
+    with _hip.tuning(gemm_variant=request.param):
+        yield request.param
 
 
 @pytest.fixture(params=[1, 2, 4, 32, 33], ids=lambda v: f"qg{v}")      # 4: the key-split latency kernel; 32 / 33: the 32 x 32 x 16 kernel (pipelined / plain) where it applies
 def attn_qg(request, built_lib):
     from vall_e.vall_e import _hip
-    _hip.set_attn_query_groups(request.param)
-    yield request.param
-    _hip.set_attn_query_groups(0)
+    with _hip.tuning(attn_query_groups=request.param):
+        yield request.param
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -119,9 +117,8 @@ def test_gemm_schedules_are_bit_identical(built_lib):
     b = torch.randn(1536, generator=g).to(torch.bfloat16).to(DEV)
     outs = []
     for v in (2, 3, 4, 5):
-        _hip.set_gemm_variant(v)
-        outs.append(_hip.op_linear(x, w, b, act=1, family=_hip.FAMILY_MFMA).clone())
-    _hip.set_gemm_variant(0)
+        with _hip.tuning(gemm_variant=v):
+            outs.append(_hip.op_linear(x, w, b, act=1, family=_hip.FAMILY_MFMA).clone())
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
@@ -143,14 +140,11 @@ def test_gemm_big_tiles_match_one_tile_kernel(built_lib, dtype, epi, M, N, K):
     r2 = torch.randn(M, N, generator=g).to(dtype).to(DEV) if epi == "r1r2" else None
     mask = (torch.rand(T, generator=g) < 0.8).to(torch.uint8).to(DEV) if epi == "r1mask" else None
     outs, arms = [], [5, 6, 7, 8]
-    try:
-        for v in arms:
-            _hip.set_gemm_variant(v)
+    for v in arms:
+        with _hip.tuning(gemm_variant=v):
             for rep in range(2):        # twice: a race between the DMA pieces and the fragment reads would not repeat
                 outs.append(_hip.op_linear(x, w, b, act=1 if epi == "gelu" else 0, r1=r1, r2=r2, row_mask=mask, mask_period=T,
                                            family=_hip.FAMILY_MFMA).clone())
-    finally:
-        _hip.set_gemm_variant(0)
     for i, o in enumerate(outs[1:]):
         assert torch.equal(outs[0], o), f"arm {arms[(i + 1) // 2]} differs on {(outs[0] != o).float().mean().item():.2e} of the elements"
     if epi in ("bias", "nobias"):
@@ -174,10 +168,9 @@ def test_gemm_persistent_matches_one_tile_kernel(built_lib, dtype, epi):
     mask = (torch.rand(T, generator=g) < 0.8).to(torch.uint8).to(DEV) if epi == "r1mask" else None
     outs = []
     for v in (5, 2, 0, 3, 4):
-        _hip.set_gemm_variant(v)
-        outs.append(_hip.op_linear(x, w, b, act=1 if epi == "gelu" else 0, r1=r1, r2=r2, row_mask=mask, mask_period=T,
-                                   family=_hip.FAMILY_MFMA).clone())
-    _hip.set_gemm_variant(0)
+        with _hip.tuning(gemm_variant=v):
+            outs.append(_hip.op_linear(x, w, b, act=1 if epi == "gelu" else 0, r1=r1, r2=r2, row_mask=mask, mask_period=T,
+                                       family=_hip.FAMILY_MFMA).clone())
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     ref = x.float() @ w.float().T + (b.float() if b is not None else 0)
     if epi == "bias" or epi == "nobias":
@@ -243,16 +236,10 @@ def test_attention_pair_vs_torch(built_lib, dtype, resident, Tq, S1, S2):
     ref1 = torch_attention(q1, kv1[..., :d], kv1[..., d:], H, scale)
     ref2 = torch_attention(q2, kv2[..., :d], kv2[..., d:], H, scale)
     tol = 4e-3 if dtype == torch.float16 else 3e-2
-    try:
-        if resident == -4:                       # the opt-in key-split kernel (attn_query_groups = 4), pair = the two halves of its grid
-            _hip.set_attn_cross_resident(0)
-            _hip.set_attn_query_groups(4)
-        else:
-            _hip.set_attn_cross_resident(resident)
+    # -4: the opt-in key-split kernel (attn_query_groups = 4), pair = the two halves of its grid
+    knobs = {"attn_cross_resident": 0, "attn_query_groups": 4} if resident == -4 else {"attn_cross_resident": resident}
+    with _hip.tuning(**knobs):
         o1, o2 = _hip.op_attention_pair(q1, kv1[..., :d], kv1[..., d:], q2, kv2[..., :d], kv2[..., d:], H, scale)
-    finally:
-        _hip.set_attn_cross_resident(1)
-        _hip.set_attn_query_groups(0)
     for name, o, ref in (("text", o1, ref1), ("prompt", o2, ref2)):
         assert torch.isfinite(o).all()
         err = (o.float() - ref).abs().max().item()
@@ -277,15 +264,12 @@ def test_attention_running_reference_moves_late(built_lib, dtype):
     scale = math.sqrt(1.0 / hd)
     ref = torch_attention(q, k, v, H, scale)
     bound = 2.0 * (_hip.op_attention(q, k, v, H, scale, family=_hip.FAMILY_GENERIC).float() - ref).abs().max().item()
-    try:
-        for qg in (2, 4, 32, 33):
-            _hip.set_attn_query_groups(qg)
+    for qg in (2, 4, 32, 33):
+        with _hip.tuning(attn_query_groups=qg):
             o = _hip.op_attention(q, k, v, H, scale).float()
-            assert torch.isfinite(o).all()
-            err = (o - ref).abs().max().item()
-            assert err < bound, f"qg{qg} {dtype}: max abs err {err} (generic kernel x 2: {bound})"
-    finally:
-        _hip.set_attn_query_groups(0)
+        assert torch.isfinite(o).all()
+        err = (o - ref).abs().max().item()
+        assert err < bound, f"qg{qg} {dtype}: max abs err {err} (generic kernel x 2: {bound})"
 
 
 def test_attention_self_packed_qkv_and_tiny_heads(built_lib):
@@ -465,13 +449,10 @@ def test_cross_attention_pair_resident_kernel_equals_the_tile_by_tile_kernel(bui
     x, fm = m.canvas_init(3)
     x[:, ::2] = torch.randint(0, 1024, x[:, ::2].shape, device=x.device, dtype=x.dtype)
     outs = []
-    try:
-        for on in (0, 4):                       # 4: resident on the 16 x 16 x 32 instruction (the 32 x 32 x 16 form accumulates in another order)
-            _hip.set_attn_cross_resident(on)
+    for on in (0, 4):                       # 4: resident on the 16 x 16 x 32 instruction (the 32 x 32 x 16 form accumulates in another order)
+        with _hip.tuning(attn_cross_resident=on):
             lg, hid = smp.denoise(x, fm, 30, kv_t, kv_p, want_hidden=True)
-            outs.append((lg.clone(), hid.clone()))
-    finally:
-        _hip.set_attn_cross_resident(1)
+        outs.append((lg.clone(), hid.clone()))
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
 
 
@@ -541,14 +522,18 @@ def test_sample_loop_is_the_same_with_and_without_row_panel_launches(built_lib):
     m = m.to(torch.bfloat16).to(DEV)
     texts, proms = synth.make_inputs(cfg, 32, 1)
     outs = []
-    try:
-        for maskbits in (0, 7, 1, 2, 4):
-            _hip.set_row_panel(maskbits)
+    for maskbits in (0, 7, 1, 2, 4):           # the stand-alone LayerNorm structure (ln_fold = 0): what the row panels fuse
+        with _hip.tuning(row_panel=maskbits, ln_fold=0):
             outs.append(m.generate_audio(texts, proms, steps=3, seed=4).clone())
-    finally:
-        _hip.set_row_panel(10)
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
+    # with the LayerNorms folded into the projections (default) the only row_panel choice left is the dual out-projection launch
+    # (bit 1: big tiles, bit 3: latency GEMM) against two launches: same bits again
+    folded = []
+    for maskbits in (10, 0):
+        with _hip.tuning(row_panel=maskbits):
+            folded.append(m.generate_audio(texts, proms, steps=3, seed=4).clone())
+    assert torch.equal(folded[0], folded[1])
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -569,15 +554,14 @@ def test_dual_out_projection_of_the_latency_regime_is_bit_identical(built_lib, d
     x, fm = m.canvas_init(batch)
     x[:, ::2] = torch.randint(0, 1024, x[:, ::2].shape, device=x.device, dtype=x.dtype)
     outs = []
-    try:
-        for maskbits in (3, 11):
-            _hip.set_row_panel(maskbits)
+    for maskbits, fold in ((3, 0), (11, 0), (2, 1), (10, 1)):      # unfolded pair, then the folded pair (two launches vs the dual launch)
+        with _hip.tuning(row_panel=maskbits, ln_fold=fold):
             lg, hid = smp.denoise(x, fm, 30, kv_t, kv_p, want_hidden=True)
             ids = m.generate_audio(texts, proms, steps=3, seed=4)
-            outs.append((lg.clone(), hid.clone(), ids.clone()))
-    finally:
-        _hip.set_row_panel(10)
+        outs.append((lg.clone(), hid.clone(), ids.clone()))
     for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[2], outs[3]):
         assert torch.equal(a, b)
 
 
@@ -608,15 +592,10 @@ def test_latency_gemm_tile_geometries_are_bit_identical(built_lib, dtype, epi, M
     if N % 8:
         kw["ldy"] = (N + 7) & ~7             # the final projection's padded logits rows
     outs = []
-    try:
-        _hip.set_gemm_variant(5)
+    with _hip.tuning(gemm_variant=5):
         outs.append(_hip.op_linear(x, w, b, family=_hip.FAMILY_MFMA, **kw).clone())
-        _hip.set_gemm_variant(4)
-        for tile in (1, 2, 3, 0):
-            _hip.set_lat_tile(tile)
+    for tile in (1, 2, 3, 0):
+        with _hip.tuning(gemm_variant=4, lat_tile=tile):
             outs.append(_hip.op_linear(x, w, b, family=_hip.FAMILY_MFMA, **kw).clone())
-    finally:
-        _hip.set_gemm_variant(0)
-        _hip.set_lat_tile(0)
     for i, o in enumerate(outs[1:]):
         assert torch.equal(outs[0], o), f"lat tile arm {i}: {(outs[0] != o).sum().item()} elements differ"

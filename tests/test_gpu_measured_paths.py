@@ -157,11 +157,8 @@ def test_vctk_shape_against_the_oracle(tag, dtype, tol_max, tol_mean, tie):
     from vall_e.vall_e import _hip
     runs = {}
     for attn, name in ((0, ""), (32, "_attn32")):
-        _hip.set_attn_query_groups(attn)
-        try:
+        with _hip.tuning(attn_query_groups=attn):
             lg, _ = smp.denoise(x, fm, 100, kv_t, kv_p)
-        finally:
-            _hip.set_attn_query_groups(0)
         nxt, _ = smp.posterior_sample(lg, x, 100, seed=seed, utt0=0)
         runs[name] = (lg.cpu(), nxt.cpu().numpy())
     conds = []
@@ -215,8 +212,9 @@ def test_vctk_shape_against_the_oracle(tag, dtype, tol_max, tol_mean, tie):
 
 # ---- (c) bf16 at the libritts shape, five timesteps --------------------------------------------------------------------
 def test_libritts_bf16_teacher_forced_at_five_timesteps():
-    """The oracle's bf16 trajectory of one utterance provides x_t at t = 99, 75, 50, 25, 1 (x_99 is the all-mask canvas,
-    the others are what the oracle's own loop produced): the HIP logits of each and the id it samples next."""
+    """The ORACLE's bf16 trajectory of one utterance provides x_t at t = 99, 75, 50, 25, 1: x_99 is the all-mask canvas, the others
+    are rows of tests/golden/libritts_bf16_trajectory.npz, written by tests/golden/make_oracle_trajectory.py from the oracle's
+    own 99-step loop on the CPU -- nothing the path under test produced.  Checked: the HIP logits at each and the id sampled next."""
     from vall_e.vall_e import _hip, synth
     cfg = synth.D3PMConfig.libritts()
     sd32 = synth.make_state_dict(cfg, 0)
@@ -232,14 +230,14 @@ def test_libritts_bf16_teacher_forced_at_five_timesteps():
     kv_t, kv_p = smp.cond_kv(ct, cp)
     with torch.no_grad():
         ocp, oct_ = orc.conditions(texts[0], proms[0])
-    # x_t along a trajectory whose denoiser runs on the GPU (99 CPU iterations of the d = 512 oracle would take minutes
-    # on the GPU box's host): the HIP loop's own trace, every step of which the other tests pin to the oracle
-    x, _ = m.canvas_init(1)
-    trace = smp.sample_loop(x, fm, 99, 0, kv_t, kv_p, seed=seed, trace=True).cpu().numpy()
+    from util import load
+    traj = load("libritts_bf16_trajectory.npz")
+    assert int(traj["seed"]) == seed
+    rows = {int(t): traj["x_t"][i].astype(np.int64) for i, t in enumerate(traj["t"])}
     x_init, _ = orc.canvas_init()
     worst, rows_bad, rows_total = 0.0, 0, 0
     for t in (99, 75, 50, 25, 1):
-        prev = x_init.numpy() if t == 99 else trace[99 - t - 1, 0].astype(np.int64)
+        prev = x_init.numpy() if t == 99 else rows[t]
         xt = torch.from_numpy(prev.astype(np.int32))[None].to(DEV)
         with torch.no_grad():
             ref = orc.logits(torch.from_numpy(prev), t, ocp, oct_, mask)
@@ -249,11 +247,8 @@ def test_libritts_bf16_teacher_forced_at_five_timesteps():
         # one utterance runs the 16 x 16 x 32 self-attention kernel; the bench batch (>= 11 utterances) the 32 x 32 x 16 one, whose
         # per-wave arithmetic does not depend on the batch: forced here, it is the measured path's kernel
         for attn, name in ((0, ""), (32, "_attn32")):
-            _hip.set_attn_query_groups(attn)
-            try:
+            with _hip.tuning(attn_query_groups=attn):
                 lg, _ = smp.denoise(xt, fm, t, kv_t, kv_p)
-            finally:
-                _hip.set_attn_query_groups(0)
             got, _ = smp.posterior_sample(lg, xt, t, seed=seed)
             got, lg = got[0].cpu().numpy(), lg[0].cpu()
             d = (lg.float() - ref.float()).abs()[: cfg.n_frames]

@@ -124,3 +124,29 @@ def test_two_stage_dp_helper_on_one_gpu(built_lib):
     tail = dp.generate_codes_dp(ar, nar, texts[1:], proms[1:], seed=5, steps=8, ar_fn=lambda t, p, **k: ar.generate_audio(t, p, **{**k, "utt0": k["utt0"] + 1}),
                                 nar_fn=lambda t, p, r, **k: nar(t, p, r, **{**k, "utt0": k["utt0"] + 1}))
     assert (tail == codes[1:]).float().mean().item() > 0.98
+
+
+def test_nar_padding_and_batch_do_not_change_an_utterance(built_lib):
+    """NAR.pad_rows_to_tiles pads the [B, t_max] grid so that B * t_max is a multiple of 192 (big-tile GEMMs); the padded
+    row count depends on the batch size, so an utterance's rows sit in different tiles in different batches.  Every GEMM
+    schedule accumulates in the same order and rows / keys past an utterance's own length are masked, so neither the padding
+    nor the batch may change a logit or an id: padded vs unpadded grid, and one utterance alone vs inside a ragged batch of
+    32 (what dp.generate_codes_dp's world-size independence rests on for the NAR stage), bit for bit."""
+    from vall_e.vall_e import synth
+    cfg, sd32, m = build(torch.bfloat16, synth.NARConfig(d_model=512, n_heads=8, n_layers=2))
+    texts, proms, resps = synth.make_nar_inputs(32, 5, t_text=(20, 50), t_prom=(100, 225), t_resp=(300, 750))
+    outs = {}
+    for pad in (True, False):
+        m.pad_rows_to_tiles = pad
+        ids, lg, lens, t_max = m(texts, proms, resps, seed=3, return_logits_level=3)
+        outs[pad] = (ids, lg, lens, t_max)
+    assert outs[True][3] != outs[False][3], "the padding did not change the grid: nothing was tested"
+    for b in range(32):
+        tt, tp, tr = (int(v) for v in outs[True][2][b])
+        rows = slice(tt + tp + 2, tt + tp + 2 + tr)
+        assert torch.equal(outs[True][1][b, rows], outs[False][1][b, rows]), f"utterance {b}: logits differ between the padded and the plain grid"
+        assert torch.equal(outs[True][0][b], outs[False][0][b]), f"utterance {b}: ids differ between the padded and the plain grid"
+    m.pad_rows_to_tiles = True
+    for b in (0, 13, 31):
+        one = m([texts[b]], [proms[b]], [resps[b]], seed=3, utt0=b)
+        assert torch.equal(one[0], outs[True][0][b]), f"utterance {b}: {(one[0] != outs[True][0][b]).sum().item()} ids differ alone vs inside the batch of 32"

@@ -552,3 +552,48 @@ def test_fp8_fast_path_agreement_with_the_16_bit_path():
         assert r["logits_rel_l2_err"] <= lim and r["teacher_forced_id_agreement"] >= 0.998, (tag, r)
     assert torch.equal(a8, m.generate_audio(texts, proms, seed=9, fp8=True)[:, live])
     assert int(a8.min()) >= 0 and int(a8.max()) <= 1024
+
+
+def test_fp8_with_16_bit_fc2_at_the_throughput_batch():
+    """The fp8 mode with fc2 left a 16-bit GEMM, at 32 utterances: the persistent block-scaled GEMM re-reads the LayerNorm block
+    scales for every tile it walks, and fc1's 16-bit output [n][2048] covers the whole shared workspace region -- the scales
+    once lived inside it and were overwritten from the second round of tiles on (at 4 utterances every workgroup had read them
+    before any store, so the small test passed by timing).  They have a workspace slot of their own now (csrc/d3pm_api.hip: ws.mxs)
+    and d3pm_op_linear_mx refuses operands that overlap its outputs.  Checked: the logits error against the 16-bit path is the
+    4-utterance test's, and four utterances of the batch run alone (told the global batch) give the same bits."""
+    import dataclasses
+    from vall_e.vall_e import _hip, synth
+    cfg = dataclasses.replace(synth.D3PMConfig.libritts(), timesteps=50)
+    m = make_model(cfg, synth.make_state_dict(cfg, 0), torch.bfloat16)
+    smp = m.sampler()
+    smp.fp8_fc2, smp._fp8 = False, None
+    texts, proms = synth.make_inputs(cfg, 32, 1)
+    ct, cp = m.encode_conditions(texts, proms)
+    kv_t, kv_p = smp.cond_kv(ct, cp)
+    x, fm = m.canvas_init(32)
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    x[:, ::2] = torch.randint(0, 1024, x[:, ::2].shape, generator=gen, dtype=x.dtype).to(x.device)
+    live = slice(0, cfg.n_frames)
+    l16 = smp.denoise(x, fm, 25, kv_t, kv_p)[0].clone()
+    l8 = smp.denoise(x, fm, 25, kv_t, kv_p, fp8=True)[0].clone()
+    rel = (l8.float() - l16.float())[:, live].norm().item() / l16.float()[:, live].norm().item()
+    per_utt = ((l8.float() - l16.float())[:, live].flatten(1).norm(dim=1) / l16.float()[:, live].flatten(1).norm(dim=1)).cpu()
+    REPORT["fp8_fc2_16bit_batch32"] = {"logits_rel_l2_err": rel, "worst_utterance_rel_l2_err": per_utt.max().item()}
+    assert rel <= 0.036 and per_utt.max().item() <= 0.05, (rel, per_utt)
+    sl = slice(20, 24)                                   # rows the later tile rounds handle
+    kv_ts, kv_ps = smp.cond_kv(ct[sl].contiguous(), cp[sl].contiguous())
+    with _hip.tuning(regime_batch=32):
+        l8s = smp.denoise(x[sl].contiguous(), fm, 25, kv_ts, kv_ps, fp8=True)[0]
+    assert torch.equal(l8s, l8[sl]), "fp8 logits of a shard differ from the same utterances inside the 32-utterance batch"
+    # the overlap check of the single op: scales placed inside the output range are refused
+    M, N, K = 192, 2048, 512
+    x8 = torch.zeros((M, K), dtype=torch.uint8, device=DEV)
+    w8 = torch.zeros((N, K), dtype=torch.uint8, device=DEV)
+    sw = torch.full((N, 4, K // 128), 127, dtype=torch.uint8, device=DEV)
+    buf = torch.zeros(M * N * 2 + 4096, dtype=torch.uint8, device=DEV)
+    y = buf[: M * N * 2].view(torch.bfloat16).view(M, N)
+    sx_inside = buf[1024: 1024 + M * 16].view(M, 4, 4)
+    with pytest.raises(_hip.D3PMError):
+        import ctypes as C
+        _hip.check(_hip.lib().d3pm_op_linear_mx(_hip.BF16, _hip._p(x8), K, _hip._p(sx_inside), _hip._p(w8), _hip._p(sw), None, _hip._p(y), N, None, 0,
+                                                None, 1, None, None, M, N, K, 0, C.byref(_hip.TUNING), _hip.stream_ptr()), "d3pm_op_linear_mx")

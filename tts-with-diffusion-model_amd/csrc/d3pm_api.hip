@@ -148,6 +148,8 @@ static int run_layernorm(const Ctx& cx, int dtype, const LayerNormArgs& a, uint3
 struct Workspace {
   char *x, *h, *h2, *qkv, *att, *att2, *mlp, *logits;
   float* stats;       // [n][d / 32][2] row moments of the residual stream (LayerNorm folded into the projections, d3pm_mfma_tile.h)
+  char* fc1f;         // [L][4d][d] fc1 under norm3 + FiLM(t), rebuilt per evaluation (d3pm_fold.hip); then fp32 [L][4d] s and b'
+  float *fc1f_s, *fc1f_b;
   uint8_t* mxs;       // fp8 fast path: block scales [2n][d / 32] of the LayerNorm rows (a slot of their own: nothing else ever lives here)
   size_t total;
 };
@@ -184,6 +186,12 @@ static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
   }
   w.stats = reinterpret_cast<float*>(take(n * ((d + 31) / 32) * 2 * sizeof(float)));
   w.mxs = reinterpret_cast<uint8_t*>(take(2 * n * ((d + 31) / 32)));
+  if (fold_shape_ok(sh.dtype, sh.d_model)) {
+    const size_t L = sh.n_layers;
+    w.fc1f = take(L * 4 * d * d * es);
+    w.fc1f_s = reinterpret_cast<float*>(take(L * 4 * d * sizeof(float)));
+    w.fc1f_b = reinterpret_cast<float*>(take(L * 4 * d * sizeof(float)));
+  }
   w.total = off;
   return w;
 }
@@ -213,7 +221,8 @@ static char* at(void* p, size_t elems, size_t es) { return static_cast<char*>(p)
 //   merged query projection <- x [norm2 | norm22 folded, N = 2d], paired cross-attention, both out-projections + x (+ moments),
 //   fc1 + GELU <- x [norm3 + FiLM(t) folded], fc2 + x, frame mask (+ moments) }: ten launches per block, none of them a LayerNorm.
 static int denoiser_blocks_folded(const d3pm_shape& sh, const d3pm_weights& w, int batch, const int32_t* x_t, const uint8_t* frame_mask,
-                                  int t, const void* kv_text, const void* kv_prompt, const Workspace& ws, int layers, hipStream_t s) {
+                                  int t, const void* film, const void* kv_text, const void* kv_prompt, const Workspace& ws, int layers,
+                                  hipStream_t s) {
   const int dt = sh.dtype, d = sh.d_model, H = sh.n_heads, hd = d / H, T = sh.canvas, n = batch * T;
   const Ctx cx(sh.tuning);
   const size_t es = dtype_size(dt);
@@ -224,6 +233,11 @@ static int denoiser_blocks_folded(const d3pm_shape& sh, const d3pm_weights& w, i
   {
     ProfScope p(cx, D3PM_K_LN, s, 0.0, es * static_cast<double>(n) * d * 2.0);
     D3PM_TRY(embed_tokens_stats(dt, e, ws.stats, s));
+  }
+  {   // fc1 of every block under norm3 + FiLM(t): the weights this evaluation's fc1 launches read
+    ProfScope p(cx, D3PM_K_LN, s, 0.0, es * 2.0 * layers * 4.0 * d * d);
+    D3PM_TRY(fold_fc1_step_launch(dt, w.blocks, layers, at(film, static_cast<size_t>(t) * sh.n_layers * 2 * d, es), d, ws.fc1f, ws.fc1f_s,
+                                  ws.fc1f_b, s));
   }
   auto folded = [&](const void* Wf, const float* fs, const float* fb, void* Y, int N, int act) -> int {
     LinearArgs g;
@@ -264,6 +278,10 @@ static int denoiser_blocks_folded(const d3pm_shape& sh, const d3pm_weights& w, i
       g.tune = cx.tune;      // one or two utterances: both products through one resident weight panel (same bits as the two launches)
       ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * 2.0 * g.M * g.N * g.K, es * (2.0 * g.M * g.K + static_cast<double>(g.N) * g.K + 2.0 * g.M * g.N));
       D3PM_TRY(panel64_dual(dt, g, ws.att2, s));
+    } else if ((tune_of(sh.tuning).row_panel & 2) && (g.tune = cx.tune, big_dual_supported(dt, g, ws.att2))) {
+      // throughput batches: the same two products through one tile of the ordinary big-tile launch (same bits again)
+      ProfScope p(cx, D3PM_K_GEMM, s, 2.0 * 2.0 * g.M * g.N * g.K, es * (2.0 * g.M * g.K + static_cast<double>(g.N) * g.K + 2.0 * g.M * g.N));
+      D3PM_TRY(big_dual(dt, g, ws.att2, s));
     } else {
       g.Y = ws.h; g.R1 = nullptr; g.stats_out = nullptr;          // o_text -> h (free: no LayerNorm output lives there any more)
       D3PM_TRY(run_linear(cx, dt, g, 0, s));
@@ -273,8 +291,8 @@ static int denoiser_blocks_folded(const d3pm_shape& sh, const d3pm_weights& w, i
       D3PM_TRY(run_linear(cx, dt, g, 0, s));
     }
     // ---- FiLM-modulated MLP: the (layer, t) copy of fc1 carries norm3 and the modulation ----
-    const size_t tn = static_cast<size_t>(t) * 4 * d;
-    D3PM_TRY(folded(at(f.fc1_w, tn * d, es), f.fc1_s + tn, f.fc1_b + tn, ws.mlp, 4 * d, ACT_GELU));
+    const size_t ln = static_cast<size_t>(l) * 4 * d;
+    D3PM_TRY(folded(at(ws.fc1f, ln * d, es), ws.fc1f_s + ln, ws.fc1f_b + ln, ws.mlp, 4 * d, ACT_GELU));
     g = LinearArgs();
     g.X = ws.mlp; g.ldx = 4 * d; g.W = b.fc2_w; g.bias = b.fc2_b; g.Y = ws.x; g.ldy = d; g.R1 = ws.x; g.ldr = d;
     g.row_mask = frame_mask; g.mask_period = T; g.M = n; g.N = d; g.K = 4 * d; g.stats_out = ws.stats;
@@ -324,7 +342,7 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
   // LayerNorm folded into the projections (d3pm_tuning.ln_fold, d3pm_fold_block): every LayerNorm-fed projection reads the raw
   // residual stream and normalises in its epilogue; every projection that lands on the residual stream leaves the row moments
   if (!use8 && w.fold && tune_of(sh.tuning).ln_fold && !(flags & D3PM_FLAG_FORCE_GENERIC) && fold_shape_ok(dt, d))
-    return denoiser_blocks_folded(sh, w, batch, x_t, frame_mask, t, kv_text, kv_prompt, ws, layers, s);
+    return denoiser_blocks_folded(sh, w, batch, x_t, frame_mask, t, film, kv_text, kv_prompt, ws, layers, s);
 
   EmbedArgs e;
   e.tokens = x_t; e.frame_mask = frame_mask; e.canvas = T; e.table = w.resps_emb; e.Y = ws.x;
@@ -578,15 +596,14 @@ int d3pm_film_table(const d3pm_shape* sh, const d3pm_weights* w, void* film, voi
 }
 
 // ---- LayerNorm folded into the projections: the tables ---------------------------------------------------------------
-struct FoldLayout { size_t qkv_w, q2_w, fc1_w, qkv_s, qkv_b, q2_s, q2_b, fc1_s, fc1_b, per_layer; };
+struct FoldLayout { size_t qkv_w, q2_w, qkv_s, qkv_b, q2_s, q2_b, per_layer; };
 static FoldLayout fold_layout(const d3pm_shape& sh) {
-  const size_t es = dtype_size(sh.dtype), d = sh.d_model, nt = static_cast<size_t>(sh.timesteps) + 1;
+  const size_t es = dtype_size(sh.dtype), d = sh.d_model;
   FoldLayout L{};
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at_ = off; off += align256(bytes); return at_; };
-  L.qkv_w = take(3 * d * d * es); L.q2_w = take(2 * d * d * es); L.fc1_w = take(nt * 4 * d * d * es);
+  L.qkv_w = take(3 * d * d * es); L.q2_w = take(2 * d * d * es);
   L.qkv_s = take(3 * d * 4); L.qkv_b = take(3 * d * 4); L.q2_s = take(2 * d * 4); L.q2_b = take(2 * d * 4);
-  L.fc1_s = take(nt * 4 * d * 4); L.fc1_b = take(nt * 4 * d * 4);
   L.per_layer = off;
   return L;
 }
@@ -596,17 +613,16 @@ size_t d3pm_fold_bytes(const d3pm_shape* sh) {
   return fold_layout(*sh).per_layer * static_cast<size_t>(sh->n_layers);
 }
 
-int d3pm_fold_build(const d3pm_shape* sh, const d3pm_weights* w, const void* film, void* storage, size_t storage_bytes,
-                    d3pm_fold_block* out, void* stream) {
+int d3pm_fold_build(const d3pm_shape* sh, const d3pm_weights* w, void* storage, size_t storage_bytes, d3pm_fold_block* out, void* stream) {
   D3PM_TRY(check_shape(sh, 1));
-  D3PM_REQUIRE(w && w->blocks && film && storage && out, D3PM_E_ARG, "d3pm_fold_build: null pointer");
+  D3PM_REQUIRE(w && w->blocks && storage && out, D3PM_E_ARG, "d3pm_fold_build: null pointer");
   D3PM_REQUIRE(fold_shape_ok(sh->dtype, sh->d_model), D3PM_E_SHAPE, "d3pm_fold_build: needs a 16-bit dtype and d_model a multiple of 256");
   const FoldLayout L = fold_layout(*sh);
   D3PM_REQUIRE(storage_bytes >= L.per_layer * sh->n_layers, D3PM_E_WORKSPACE, "d3pm_fold_build: storage %zu < required %zu", storage_bytes,
                L.per_layer * static_cast<size_t>(sh->n_layers));
   D3PM_REQUIRE(reinterpret_cast<uintptr_t>(storage) % 256 == 0, D3PM_E_ARG, "d3pm_fold_build: storage must be 256-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int dt = sh->dtype, d = sh->d_model, nt = sh->timesteps + 1;
+  const int dt = sh->dtype, d = sh->d_model;
   const size_t es = dtype_size(dt);
   for (int l = 0; l < sh->n_layers; ++l) {
     const d3pm_block_weights& b = w->blocks[l];
@@ -617,13 +633,9 @@ int d3pm_fold_build(const d3pm_shape* sh, const d3pm_weights* w, const void* fil
     D3PM_TRY(fold_rows_launch(dt, b.cross_in_w, b.cross_in_b, b.norm2_w, b.norm2_b, nullptr, 0, d, 1, d, base + L.q2_w, f32(L.q2_s), f32(L.q2_b), s));
     D3PM_TRY(fold_rows_launch(dt, b.cross_in_w, b.cross_in_b, b.norm22_w, b.norm22_b, nullptr, 0, d, 1, d, base + L.q2_w + static_cast<size_t>(d) * d * es,
                               f32(L.q2_s) + d, f32(L.q2_b) + d, s));
-    // fc1 under norm3 + FiLM(t): film[t][l] = (scale | shift), rows strided by n_layers * 2d
-    D3PM_TRY(fold_rows_launch(dt, b.fc1_w, b.fc1_b, b.norm3_w, b.norm3_b, at(film, static_cast<size_t>(l) * 2 * d, es),
-                              static_cast<long>(sh->n_layers) * 2 * d, 4 * d, nt, d, base + L.fc1_w, f32(L.fc1_s), f32(L.fc1_b), s));
     d3pm_fold_block& o = out[l];
     o.qkv_w = base + L.qkv_w; o.qkv_s = f32(L.qkv_s); o.qkv_b = f32(L.qkv_b);
     o.q2_w = base + L.q2_w; o.q2_s = f32(L.q2_s); o.q2_b = f32(L.q2_b);
-    o.fc1_w = base + L.fc1_w; o.fc1_s = f32(L.fc1_s); o.fc1_b = f32(L.fc1_b);
   }
   return D3PM_OK;
 }

@@ -5,10 +5,12 @@
 // norm1 -> attn in-projection, :136-142 norm2 | norm22 -> cross_attn's query rows, :145-159 norm3 + FiLM -> mlp.fc1), so
 //     LN(x) W^T + b = rstd_r (x_r . W'^T - mean_r s) + b',   W' = W o gamma,  s_n = sum_k W'[n][k],  b' = W beta + b
 // (d3pm_mfma_tile.h, EPI_LNF).  With FiLM the per-column factor is gamma_k rn(1 + scale_t[k]) and the constant
-// beta_k rn(1 + scale_t[k]) + shift_t[k]: it depends on the timestep, so fc1 gets one W' per (layer, t) -- (timesteps + 1) x
-// 4d x d elements per layer, 1.27 GB for the 100-step d = 512 model, built once per weight set next to d3pm_film_table and read
-// at 2 MB per launch.  W' is rounded to the storage type once here; s is summed over the ROUNDED W' (so that
-// x . W' - mean s cancels exactly what the matrix pipe accumulated), b' over the unrounded products, both in fp32.
+// beta_k rn(1 + scale_t[k]) + shift_t[k]: it depends on the timestep, so fc1's W' is rebuilt for the timestep at the top of every
+// denoiser evaluation -- ONE launch for all layers, 2 x 12 MB through the chip at d = 512 (~6 us), into the caller's workspace.
+// (A table of every (layer, t) copy, 1.27 GB, was measured first: each fc1 launch then streamed its 2 MB from HBM cold and ran
+// 7.5 us slower than with the weights resident in the Infinity Cache -- 45 us per iteration against the 6 of rebuilding.)
+// W' is rounded to the storage type once; s is summed over the ROUNDED W' (so that x . W' - mean s cancels exactly what the matrix
+// pipe accumulated), b' over the unrounded products, both in fp32.
 #include "d3pm_kernels.h"
 
 namespace d3pm {
@@ -57,6 +59,47 @@ __global__ __launch_bounds__(256) void fold_rows(const T* __restrict__ W, const 
   }
 }
 
+// fc1 of every layer at one timestep, one launch: row r = (layer r / n_rows, output n = r % n_rows); film_t = film[t] = [L][2K]
+struct FoldStepPtrs { const void* W[16]; const void* bias[16]; const void* gamma[16]; const void* beta[16]; };
+template <typename T>
+__global__ __launch_bounds__(256) void fold_rows_layers(FoldStepPtrs p, const T* __restrict__ film_t, int n_rows, int n_layers, int K,
+                                                        T* __restrict__ Wf, float* __restrict__ s_out, float* __restrict__ b_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= n_rows * n_layers) return;
+  const int l = r / n_rows, n = r % n_rows;
+  const T* wrow = static_cast<const T*>(p.W[l]) + static_cast<size_t>(n) * K;
+  const T* gamma = static_cast<const T*>(p.gamma[l]);
+  const T* beta = static_cast<const T*>(p.beta[l]);
+  const T* frow = film_t + static_cast<size_t>(l) * 2 * K;
+  T* orow = Wf + static_cast<size_t>(r) * K;
+  float s = 0.f, b = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const Vec8<T> w8 = *reinterpret_cast<const Vec8<T>*>(wrow + k), g8 = *reinterpret_cast<const Vec8<T>*>(gamma + k),
+                  b8 = *reinterpret_cast<const Vec8<T>*>(beta + k), sc8 = *reinterpret_cast<const Vec8<T>*>(frow + k),
+                  sh8 = *reinterpret_cast<const Vec8<T>*>(frow + K + k);
+    Vec8<T> o8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {          // the arithmetic of fold_rows with FiLM, statement for statement
+      const float w = static_cast<float>(w8.v[i]);
+      float g = static_cast<float>(g8.v[i]), c = static_cast<float>(b8.v[i]);
+      const float gg = rn<T>(1.0f + static_cast<float>(sc8.v[i]));
+      g *= gg;
+      c = __builtin_fmaf(c, gg, static_cast<float>(sh8.v[i]));
+      o8.v[i] = static_cast<T>(w * g);
+      s += static_cast<float>(o8.v[i]);
+      b = __builtin_fmaf(w, c, b);
+    }
+    *reinterpret_cast<Vec8<T>*>(orow + k) = o8;
+  }
+  s = wave_sum(s);
+  b = wave_sum(b);
+  if (lane == 0) {
+    s_out[r] = s;
+    b_out[r] = b + static_cast<float>(static_cast<const T*>(p.bias[l])[n]);
+  }
+}
+
 // (sum, sum of squares) of every 32-column part of every row: stats[M][d / 32][2].  One wave per row, lane L of pass j owns the
 // 16-byte chunk 64 j + L; the four lanes of a quad own one part.  Used where the residual rows do not come out of a GEMM epilogue:
 // the token embedding in front of the first block (ar_discrete.py:753), and as a stand-alone op for tests.
@@ -65,8 +108,10 @@ __device__ __forceinline__ void part_moments(const Vec8<T>& raw, float& a, float
   float v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(raw.v[i]);
-  a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-  q = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+  a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));      // = part_moments8 of d3pm_mfma_tile.h
+  q = v[7] * v[7];
+#pragma unroll
+  for (int i = 6; i >= 0; --i) q = __builtin_fmaf(v[i], v[i], q);
   // the order of the GEMM epilogues (d3pm_mfma_tile.h emit_stats: columns 0-7 + 16-23, then + (8-15 + 24-31)), so that the moments
   // of a row are the same bits whichever kernel produced them
   a = add_dpp<0x4E>(a); q = add_dpp<0x4E>(q);     // lane ^ 2
@@ -129,6 +174,31 @@ int fold_rows_launch(int dtype, const void* W, const void* bias, const void* gam
     fold_rows<bf16><<<grid, block, 0, s>>>(static_cast<const bf16*>(W), static_cast<const bf16*>(bias), static_cast<const bf16*>(gamma),
                                            static_cast<const bf16*>(beta), static_cast<const bf16*>(film), film_ld, n_rows, n_t, K,
                                            static_cast<bf16*>(Wf), s_out, b_out);
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+// fc1 of every block under norm3 + FiLM(t) (ar_discrete.py:145-159): blocks HOST array; film_t = row t of the FiLM table
+int fold_fc1_step_launch(int dtype, const d3pm_block_weights* blocks, int n_layers, const void* film_t, int d, void* Wf, float* s_out,
+                         float* b_out, hipStream_t s) {
+  if (n_layers > 16) {           // beyond the pointer table of one launch: layer by layer
+    const size_t es = dtype_size(dtype);
+    for (int l = 0; l < n_layers; ++l) {
+      const int rc = fold_rows_launch(dtype, blocks[l].fc1_w, blocks[l].fc1_b, blocks[l].norm3_w, blocks[l].norm3_b,
+                                      static_cast<const char*>(film_t) + static_cast<size_t>(l) * 2 * d * es, 0, 4 * d, 1, d,
+                                      static_cast<char*>(Wf) + static_cast<size_t>(l) * 4 * d * d * es, s_out + static_cast<size_t>(l) * 4 * d,
+                                      b_out + static_cast<size_t>(l) * 4 * d, s);
+      if (rc != D3PM_OK) return rc;
+    }
+    return D3PM_OK;
+  }
+  FoldStepPtrs p{};
+  for (int l = 0; l < n_layers; ++l) { p.W[l] = blocks[l].fc1_w; p.bias[l] = blocks[l].fc1_b; p.gamma[l] = blocks[l].norm3_w; p.beta[l] = blocks[l].norm3_b; }
+  const dim3 grid(static_cast<unsigned>((4 * d * n_layers + 3) / 4)), block(256);
+  if (dtype == D3PM_F16)
+    fold_rows_layers<f16><<<grid, block, 0, s>>>(p, static_cast<const f16*>(film_t), 4 * d, n_layers, d, static_cast<f16*>(Wf), s_out, b_out);
+  else
+    fold_rows_layers<bf16><<<grid, block, 0, s>>>(p, static_cast<const bf16*>(film_t), 4 * d, n_layers, d, static_cast<bf16*>(Wf), s_out, b_out);
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;
 }

@@ -193,6 +193,9 @@ int ln_prologue_linear(int dtype, const LinearArgs& a, const LnPrologue& ln, hip
 // latency GEMM, two products through one weight panel: Y = rn(rn(R1 + rn(X W^T + b)) + rn(X2 W^T + b)) (d3pm_mfma_gemm_lat.hip)
 bool panel64_dual_supported(int dtype, const LinearArgs& a, const void* X2);
 int panel64_dual(int dtype, const LinearArgs& a, const void* X2, hipStream_t s);
+// big-tile GEMM, the same two products at throughput batch sizes (d3pm_mfma_gemm_big.hip); stats_out optional
+bool big_dual_supported(int dtype, const LinearArgs& a, const void* X2);
+int big_dual(int dtype, const LinearArgs& a, const void* X2, hipStream_t s);
 bool row_panel_supported(int dtype, const LinearArgs& a, const RowPanelFuse& f);
 int row_panel_linear(int dtype, const LinearArgs& a, const RowPanelFuse& f, hipStream_t s);
 bool fast_layernorm_supported(int dtype, const LayerNormArgs& a);
@@ -204,6 +207,8 @@ PosteriorConsts make_posterior_consts(const d3pm_schedule* sched, int t);
 bool fold_shape_ok(int dtype, int d);
 int fold_rows_launch(int dtype, const void* W, const void* bias, const void* gamma, const void* beta, const void* film, long film_ld,
                      int n_rows, int n_t, int K, void* Wf, float* s_out, float* b_out, hipStream_t s);
+int fold_fc1_step_launch(int dtype, const d3pm_block_weights* blocks, int n_layers, const void* film_t, int d, void* Wf, float* s_out,
+                         float* b_out, hipStream_t s);
 int row_stats_launch(int dtype, const void* x, int ldx, int M, int d, float* stats, hipStream_t s);
 int embed_tokens_stats(int dtype, const EmbedArgs& a, float* stats, hipStream_t s);
 

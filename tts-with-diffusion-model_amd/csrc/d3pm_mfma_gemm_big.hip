@@ -80,6 +80,8 @@ template <typename T> struct RowPanelArgs {
 };
 constexpr int FUSE_DUAL = 1, FUSE_LN = 2, FUSE_LN2 = 4, FUSE_FILM = 8, FUSE_ABL_NOLN = 16, FUSE_MX = 32;   // 16: timing-only (LayerNorm arithmetic skipped)
 
+template <int EPI> constexpr bool kLnfPreDecl = (EPI & EPI_LNF) != 0;
+
 template <typename T, int EPI, int WM, int WN, int MODE, int FUSE = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                         const T* __restrict__ bias, T* Y, int ldy, const T* R1,
@@ -103,13 +105,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   // residual read runs under the k-loop instead of after it.  NPRE = the vector-memory operations this certainly adds behind
   // the previous tile's stores (a LOWER bound keeps the counted waits safe: they may only wait for more): 12 residual + 6 mask loads
   constexpr bool kPreEpi = (MODE & 32768) != 0 && FUSE == 0 && (EPI & EPI_R2) == 0;
+  // EPI_LNF (K = 512: the launcher): the row moments a lane needs for its six row blocks are 12 x 16 bytes per tile -- 48 KB per
+  // workgroup tile beside its 320 KB of operands, through the same CU <-> L2 path -- and a round trip the epilogue would start
+  // with.  Loaded where the epilogue needs them they cost qkv 36.7 -> 45.1 us and fc1 69.7 -> 84.8 us in the loop; requested at
+  // the top of the tile they stalled the second k-step instead (every k-step waits with vmcnt(0), vector-memory operations
+  // retire in order).  The one place such a load can hide is ACROSS an epilogue: the moments of the NEXT row panel are requested
+  // at the start of the epilogue of the last tile of this one, from inline asm (exactly 12 loads) behind the tile's own
+  // per-column vectors (8 asm loads), the epilogue waits with vmcnt(12) -- its vectors have landed, the moments may stay in
+  // flight -- and the next tile's first k-step, which waits for everything older than the 12 output stores anyway, finds them
+  // landed; they are reduced to the two scalars per row right behind that k-step.  Together with the consecutive tile walk
+  // (below) the folded launch is within 1-2 us of the plain one on cold operands (tests/ab_fold.py).
+  constexpr bool kLnfPre = (EPI & EPI_LNF) != 0;
   constexpr int NPRE = !kPreEpi ? 0 : ((EPI & EPI_R1) ? 12 : 0) + ((EPI & EPI_MASK) ? 6 : 0);
   static_assert((MODE & 32768) == 0 || (!kDrip && (MODE & 1)), "epilogue prefetch rides in the hand-placed schedule");
   constexpr bool kDual = (FUSE & FUSE_DUAL) != 0, kLn = (FUSE & FUSE_LN) != 0, kLn2 = (FUSE & FUSE_LN2) != 0, kFilm = (FUSE & FUSE_FILM) != 0;
   constexpr bool kMx = (FUSE & FUSE_MX) != 0;
   static_assert(!kMx || kLn, "the MX output is the LayerNorm output");
-  static_assert(FUSE == 0 || (WM == 1 && WN == 8 && !kDrip && (MODE & 1)), "row-panel fusion: 96 x 512 tiles, hand-placed schedule");
-  static_assert((EPI & (EPI_LNF | EPI_STATS)) == 0 || (FUSE == 0 && !kDrip && !kPreEpi), "the folded-LayerNorm epilogues ride in the plain launches");
+  static_assert(FUSE == 0 || !kDrip, "fusions ride in the hand-placed schedule without deferred stores");
+  static_assert(FUSE == 0 || FUSE == FUSE_DUAL || (WM == 1 && WN == 8 && (MODE & 1)), "row-panel fusion: 96 x 512 tiles, hand-placed schedule");
+  static_assert((EPI & (EPI_LNF | EPI_STATS)) == 0 || ((FUSE == 0 || (FUSE == FUSE_DUAL && (EPI & EPI_LNF) == 0)) && !kDrip && !kPreEpi),
+                "the folded-LayerNorm epilogues ride in the plain launches (and the row moments in the dual out-projection)");
   static_assert(!kLn2 || kLn, "the second LayerNorm shares the moments of the first");
   static_assert(!kDrip || kHand, "deferred stores ride in the hand-placed schedule");
   constexpr int SPS = 12 - NDMA;                        // deferred stores per k-step: the MFMA groups behind the last DMA piece
@@ -126,7 +141,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   const int tq = tiles_total >> 3, tr = tiles_total & 7;
   const int lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, cnt = tq + (xcd < tr ? 1 : 0);
   int t = blockIdx.x >> 3;
-  if (t >= cnt) return;                                              // block-uniform
+  // EPI_LNF: a workgroup walks CONSECUTIVE tiles -- n-tiles of one row panel (3 of the 12 of the qkv projection, 4 of fc1's 16) --
+  // instead of every per_xcd-th one, so the row scalars of a panel are fetched and reduced once per workgroup, not once per tile
+  // (in the loop 102.2 k -> 103.4 k tokens/s; for the other epilogues the walk order measured no difference and stays as it was)
+  constexpr bool consec = kLnfPreDecl<EPI>;
+  const int t_per = (cnt + per_xcd - 1) / per_xcd;
+  const int t_end = consec ? ((t + 1) * t_per < cnt ? (t + 1) * t_per : cnt) : cnt, t_step = consec ? 1 : per_xcd;
+  if (consec) t *= t_per;
+  if (t >= t_end) return;                                            // block-uniform
   if constexpr ((MODE & (8192 | 16384)) != 0) {
     // A/B: de-synchronise the chip-wide output burst -- the workgroups of every second XCD start later by a fraction of a tile
     // (bits 13 / 14 / both: ~2 / 4 / 6 us; one s_sleep 127 measured ~3.1 us), so that one group's stores drain while the other
@@ -178,6 +200,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   const T* sw = W + static_cast<size_t>((tile % n_tiles) * TN) * K;
 #pragma unroll
   for (int p = 0; p < NDMA; ++p) dma(p, sx, sw, lds_base);          // first k-step of the first tile
+  [[maybe_unused]] floatx4 lst[6][2];                                // EPI_LNF: the moments of the tile about to start, in flight
+  auto moments_request = [&](int mrow0) __attribute__((always_inline)) {
+    const float* sp = ef.stats_in + (static_cast<size_t>(mrow0 + wm * 96 + (lane & 15)) * 16 + (lane >> 4) * 4) * 2;
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt) {
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lst[mt][0]) : "v"(sp + mt * 16 * 32) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(lst[mt][1]) : "v"(sp + mt * 16 * 32) : "memory");
+    }
+  };
+  if constexpr (kLnfPre) moments_request((tile / n_tiles) * TM);     // the first tile's: covered by the wait below
+  [[maybe_unused]] RowScalars<6> rows;
+  [[maybe_unused]] bool fresh = true;                                // lst holds moments that have not been reduced yet
   // the first step of a tile waits with vmcnt(12): behind an epilogue the DMA pieces are older than its 12 stores; the very
   // first tile has no stores behind its pieces, so they are waited for here
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -196,8 +230,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
     [[maybe_unused]] EpiPre<T, 4, 6> pre;
     if constexpr (kPreEpi) epilogue_prefetch<T, EPI, 4, 6>(pre, bias, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96, n0 + wn * 64, lane);
     // what follows this tile (block-uniform); the last tile re-reads its own first k-step: valid memory, never used
-    const int t_next = t + per_xcd;
-    const bool more = t_next < cnt;
+    const int t_next = t + t_step;
+    const bool more = t_next < t_end;
     const int tile_next = more ? lo + t_next : tile;
     const T* sx_next = X + static_cast<size_t>((tile_next / n_tiles) * TM) * ldx;
     const T* sw_next = W + static_cast<size_t>((tile_next % n_tiles) * TN) * K;
@@ -317,6 +351,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
     // the nk k-steps of one product: operand rows `ax`, weights `sw`; (nx, nw) = the first k-step of whatever follows
     auto run_k = [&](const T* ax, const T* nx, const T* nw, auto FIRSTW) __attribute__((always_inline)) {
       step(I0{}, FIRSTW, I0{}, I0{}, ax + BK, sw + BK);
+      if constexpr (kLnfPre) {
+        // the first k-step waited for everything older than the previous tile's stores: this tile's moments, requested in front of
+        // those stores, have landed (the "+v" operands keep every use behind that wait)
+        if (fresh)
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+          asm volatile("" : "+v"(lst[mt][0]), "+v"(lst[mt][1]));
+          const floatx4 p0 = lst[mt][0], p1 = lst[mt][1];
+          float a = 0.f, q = 0.f;
+          a += p0[0]; q += p0[1]; a += p0[2]; q += p0[3];
+          a += p1[0]; q += p1[1]; a += p1[2]; q += p1[3];
+          a = add_xor16(a); q = add_xor16(q);
+          fold_row_scalars(add_xor32(a), add_xor32(q), 512, ef.eps, rows.ra[mt], rows.rc[mt]);
+        }
+      }
       step(I1{}, I0{}, I0{}, I0{}, ax + 2 * BK, sw + 2 * BK);
       for (int kt = 2; kt < nk; kt += 2) {                  // nk is even and >= 4
         step(I0{}, I0{}, I0{}, I0{}, ax + (kt + 1) * BK, sw + (kt + 1) * BK);
@@ -348,7 +397,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
         const bool mid = ph == 0;
         run_k(ax, mid ? sx2 : sx_next, mid ? sw : sw_next, std::integral_constant<int, 12>{});
         if (mid) {
-          epilogue_store<T, 0, 4, 6, true, true>(acc, bias, Y, ldy, nullptr, nullptr, ldr, nullptr, 1, M, N, m0, n0 + wn * 64, lane, h1p);
+          epilogue_store<T, 0, 4, 6, true, true>(acc, bias, Y, ldy, nullptr, nullptr, ldr, nullptr, 1, M, N, m0 + wm * 96, n0 + wn * 64, lane, h1p);
 #pragma unroll
           for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -364,8 +413,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
       uintx4 xp[12];
       if constexpr (kDual) {
         // x' = rn(rn(R1 + h) + rn(X2 W^T + b)): the R1 + R2 epilogue of the two-launch form with R2 = h taken from registers
-        epilogue_store<T, 0, 4, 6, true, true>(acc, bias, Y, ldy, nullptr, nullptr, ldr, nullptr, 1, M, N, m0, n0 + wn * 64, lane, xp);
-        const T* r1row = R1 + static_cast<size_t>(m0 + (lane & 15)) * ldr + n0 + wn * 64 + epilogue_nq(lane);
+        epilogue_store<T, 0, 4, 6, true, true>(acc, bias, Y, ldy, nullptr, nullptr, ldr, nullptr, 1, M, N, m0 + wm * 96, n0 + wn * 64, lane, xp);
+        const T* r1row = R1 + static_cast<size_t>(m0 + wm * 96 + (lane & 15)) * ldr + n0 + wn * 64 + epilogue_nq(lane);
         Pack8<T> r1p[12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) r1p[j] = *reinterpret_cast<const Pack8<T>*>(r1row + static_cast<size_t>((j / 2) * 16) * ldr + (j % 2) * 32);
@@ -383,9 +432,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
       }
       // ---- the finished rows: store x', then LayerNorm them in place (layernorm_vec's arithmetic, bit for bit)
       const int g = lane >> 4, nq = epilogue_nq(lane);
-      T* yrow = Y + static_cast<size_t>(m0 + (lane & 15)) * ldy + n0 + wn * 64 + nq;
+      T* yrow = Y + static_cast<size_t>(m0 + wm * 96 + (lane & 15)) * ldy + n0 + wn * 64 + nq;
 #pragma unroll
       for (int j = 0; j < 12; ++j) *reinterpret_cast<uintx4*>(yrow + static_cast<size_t>((j / 2) * 16) * ldy + (j % 2) * 32) = xp[j];
+      if constexpr ((EPI & EPI_STATS) != 0) {        // the row moments of the new rows for the folded LayerNorm that reads them next
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+          const Pack8<T> p = __builtin_bit_cast(Pack8<T>, xp[j]);
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(p.v[i]);
+          part_stats_store(v, ef.stats_out, static_cast<size_t>(m0 + wm * 96 + (j / 2) * 16 + (lane & 15)), N, n0 + wn * 64 + (j % 2) * 32, g, true);
+        }
+      }
       if constexpr (kLn && (FUSE & FUSE_ABL_NOLN) != 0) {      // timing-only: the stores of the LayerNorm outputs without their arithmetic
 #pragma unroll
         for (int np = 0; np < 2; ++np)
@@ -539,7 +598,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
           kept = true;
         }
       }
-      if (!kept)
+      if constexpr (kLnfPre) {
+        floatx4 bq[4], sq[4];
+        const int ncol = n0 + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[nt]) : "v"(ef.b + ncol + nt * 16) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sq[nt]) : "v"(ef.s + ncol + nt * 16) : "memory");
+        }
+        fresh = more && (tile_next / n_tiles) != (tile / n_tiles);      // the next tile reads other rows
+        if (fresh) {
+          moments_request((tile_next / n_tiles) * TM);
+          asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          asm volatile("" : "+v"(bq[nt]), "+v"(sq[nt]));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pre.bv[nt][r] = bq[nt][r]; pre.sv[nt][r] = sq[nt][r]; }
+        }
+        epilogue_store<T, EPI, 4, 6, true, false, false, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
+                                                               n0 + wn * 64, lane, nullptr, gelu_tab, &pre, &ef, &rows);
+      } else if (!kept)
         epilogue_store<T, EPI, 4, 6, true, false, (MODE & 512) != 0, kPreEpi>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
                                                                               n0 + wn * 64, lane, nullptr, gelu_tab, &pre, &ef);
     }
@@ -586,7 +668,7 @@ int big_linear_tile(int dtype, const LinearArgs& a, int want) {
   if (a.ldx % 8 != 0 || a.ldy % 8 != 0 || !aligned16(a.X) || !aligned16(a.W) || !aligned16(a.Y)) return 0;
   if (a.R1 && (a.ldr % 8 != 0 || !aligned16(a.R1))) return 0;
   if (a.R2 && (!a.R1 || !aligned16(a.R2))) return 0;
-  if (!fold_args_ok(a)) return 0;
+  if (!fold_args_ok(a) || (a.fold_s && a.K != 512)) return 0;      // the big tile prefetches the 16 moment parts of a 512-wide row
   const bool gelu = a.act == ACT_GELU, r1 = a.R1 != nullptr, r2 = a.R2 != nullptr, mk = a.row_mask != nullptr;
   if (a.act != ACT_NONE && !gelu) return 0;
   if (gelu && (r1 || mk)) return 0;                       // instantiated epilogues: plain, GELU, R1, R1+R2, R1+mask
@@ -720,6 +802,45 @@ static int big_launch_fold(int id, const LinearArgs& a, int n_tiles, int tiles_t
   if (id == 1) return big_launch<U, E, 1, 8, 1>(a, n_tiles, tiles_total, grid, lds, s);
   if (id == 2) return big_launch<U, E, 2, 4, 1>(a, n_tiles, tiles_total, grid, lds, s);
   return big_launch<U, E, 2, 2, 1>(a, n_tiles, tiles_total, grid, lds, s);
+}
+
+// Both cross-attention out-projections (ar_discrete.py:138,142: the SAME weights) in one launch of the ordinary big-tile geometry:
+// a second product through the tile, the first result kept packed in 48 registers, x' = rn(rn(R1 + rn(X W^T + b)) + rn(X2 W^T + b))
+// -- the bits of the two launches it replaces -- and, with stats_out, the row moments of x' for the folded norm3 of fc1.
+bool big_dual_supported(int dtype, const LinearArgs& a, const void* X2) {
+  if (!X2 || !aligned16(X2) || !a.R1 || a.R2 || a.row_mask || a.act != ACT_NONE || !a.bias || a.fold_s) return false;
+  return big_linear_tile(dtype, a, tune_of(a.tune).gemm_variant == 6 ? 2 : tune_of(a.tune).gemm_variant == 8 ? 3 : 0) >= 2;
+}
+
+template <typename U, int E, int WM, int WN>
+static int big_dual_launch(const LinearArgs& a, const void* X2, int n_tiles, int tiles_total, dim3 grid, size_t lds, hipStream_t s) {
+  D3PM_LDS_ATTR((&gemm_mfma_big<U, E, WM, WN, 1, FUSE_DUAL>), 160 * 1024);
+  RowPanelArgs<U> rp{};
+  rp.X2 = static_cast<const U*>(X2);
+  gemm_mfma_big<U, E, WM, WN, 1, FUSE_DUAL><<<grid, dim3(WM * WN * 64), lds, s>>>(
+      static_cast<const U*>(a.X), a.ldx, static_cast<const U*>(a.W), static_cast<const U*>(a.bias), static_cast<U*>(a.Y), a.ldy,
+      static_cast<const U*>(a.R1), nullptr, a.ldr, nullptr, 1, a.M, a.N, a.K, n_tiles, tiles_total, nullptr, rp, epi_fold_of(a));
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+int big_dual(int dtype, const LinearArgs& a, const void* X2, hipStream_t s) {
+  const int id = big_linear_tile(dtype, a, tune_of(a.tune).gemm_variant == 6 ? 2 : tune_of(a.tune).gemm_variant == 8 ? 3 : 0);
+  int tm, tn, waves;
+  big_geometry(id, tm, tn, waves);
+  const int n_tiles = a.N / tn, tiles_total = (a.M / tm) * n_tiles;
+  const int slots = 256 * (8 / waves), want = (tiles_total + 7) & ~7;
+  const dim3 grid(static_cast<unsigned>(want < slots ? want : slots));
+  const size_t lds = 2 * static_cast<size_t>(tm + tn) * ROW_BYTES;
+  auto go = [&](auto* tag) -> int {
+    using U = std::remove_pointer_t<decltype(tag)>;
+    if (a.stats_out)
+      return id == 2 ? big_dual_launch<U, EPI_R2 | EPI_STATS, 2, 4>(a, X2, n_tiles, tiles_total, grid, lds, s)
+                     : big_dual_launch<U, EPI_R2 | EPI_STATS, 2, 2>(a, X2, n_tiles, tiles_total, grid, lds, s);
+    return id == 2 ? big_dual_launch<U, EPI_R2, 2, 4>(a, X2, n_tiles, tiles_total, grid, lds, s)
+                   : big_dual_launch<U, EPI_R2, 2, 2>(a, X2, n_tiles, tiles_total, grid, lds, s);
+  };
+  return dtype == D3PM_F16 ? go(static_cast<f16*>(nullptr)) : go(static_cast<bf16*>(nullptr));
 }
 
 int big_linear(int dtype, const LinearArgs& a, int id, hipStream_t s) {

@@ -242,15 +242,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mfma_panel64(const T* __restrict_
       float v[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(o.v[i]);
-      float a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      float q = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
-      a = add_xor16(a); q = add_xor16(q);
-      a = add_xor32(a); q = add_xor32(q);
-      if (lane < 16) {
-        typedef float float2v __attribute__((ext_vector_type(2)));
-        const size_t m = static_cast<size_t>(m0 + wm * (TM / 2) + lane);
-        *reinterpret_cast<float2v*>(ef.stats_out + (m * (N >> 5) + ((n0 + wn * (TN / 2)) >> 5)) * 2) = float2v{a, q};
-      }
+      part_stats_store(v, ef.stats_out, static_cast<size_t>(m0 + wm * (TM / 2) + (lane & 15)), N, n0 + wn * (TN / 2), lane >> 4, true);
     }
     return;
   }

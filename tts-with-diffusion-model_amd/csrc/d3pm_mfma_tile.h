@@ -132,6 +132,34 @@ __device__ __forceinline__ void fold_row_moments(const float* __restrict__ stats
   a = add_xor16(a); q = add_xor16(q);
   s1 = add_xor32(a); s2 = add_xor32(q);
 }
+// the in-lane half of a part's moments: eight consecutive columns.  a: pairwise tree; q: one fused chain (v7^2 first)
+__device__ __forceinline__ void part_moments8(const float (&v)[8], float& a, float& q) {
+  a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  q = v[7] * v[7];
+#pragma unroll
+  for (int i = 6; i >= 0; --i) q = __builtin_fmaf(v[i], v[i], q);
+}
+
+// EPI_STATS: (sum, sum of squares) of the 32 stored values of row m in the 32-column part starting at column `col0` -- eight in this
+// lane, the other 24 in the lanes 16 / 32 / 48 away.  The order below is the definition of a part's moments for every kernel
+// (and of d3pm_op_row_stats, d3pm_fold.hip).  Executed by the whole wave (lane permutes); `ok` only predicates the store.
+__device__ __forceinline__ void part_stats_store(const float (&v)[8], float* __restrict__ stats_out, size_t m, int N, int col0, int g, bool ok) {
+  float a, q;
+  part_moments8(v, a, q);
+  // one butterfly for both moments: after the 16-lane swap the even lane rows hold sums of `a`, the odd ones sums of `q`
+  //   rows (a0, a1, a2, a3) | (q0, q1, q2, q3)  --swap16-->  (a0, q0, a2, q2) | (a1, q1, a3, q3)  --add-->  (a01, q01, a23, q23)
+  // and after the 32-lane swap of two copies of that: (a01 + a23, q01 + q23, ..): lane group 0 ends with sum, group 1 with sum of squares
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(q));
+  float z = a + q, z2 = z;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(z), "+v"(z2));
+  z += z2;
+  if (g < 2 && ok) stats_out[(m * (N >> 5) + (col0 >> 5)) * 2 + g] = z;
+}
+
+// per-row scalars of EPI_LNF computed ahead of the epilogue (big-tile GEMM: the moments are requested at the top of a tile and
+// reduced under the k-loop, so that the epilogue does not start with a dependent round trip to memory)
+template <int MT> struct RowScalars { float ra[MT], rc[MT]; };
+
 // the two per-row scalars of EPI_LNF: y = fma(acc, ra, fma(rc, s_n, b'_n)) with ra = rstd, rc = -mean rstd
 __device__ __forceinline__ void fold_row_scalars(float s1, float s2, int d, float eps, float& ra, float& rc) {
   const float inv_d = 1.0f / static_cast<float>(d);
@@ -249,7 +277,8 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
                                                int mask_period, int M, int N, int mw0, int nw0, int lane,
                                                uintx4* packed = nullptr, const uint16_t* gelu_tab = nullptr,
                                                const EpiPre<T, NT, MT>* pre = nullptr,      // pre: read only when kPre
-                                               const EpiFold* ef = nullptr) {               // ef: read only under EPI_LNF / EPI_STATS
+                                               const EpiFold* ef = nullptr,                 // ef: read only under EPI_LNF / EPI_STATS
+                                               const RowScalars<MT>* rows = nullptr) {      // EPI_LNF: the row scalars, when the caller has them
   static_assert(!kPack || kInteriorOnly, "packing to registers is for whole tiles");
   static_assert(NT % 2 == 0, "column blocks are regrouped in pairs");
   constexpr bool kGelu = EPI & EPI_GELU, kR1 = (EPI & (EPI_R1 | EPI_R2)) != 0, kR2 = (EPI & EPI_R2) != 0, kMask = (EPI & EPI_MASK) != 0;
@@ -280,7 +309,10 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
       }
     }
     const int d_in = ef->parts_in * 32;
-    if (kPre && ef->parts_in == 16) {
+    if (rows != nullptr) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { ra[mt] = rows->ra[mt]; rc[mt] = rows->rc[mt]; }
+    } else if (kPre && ef->parts_in == 16) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const floatx4 p0 = pre->st[mt][0], p1 = pre->st[mt][1];
@@ -351,17 +383,8 @@ __device__ __forceinline__ void epilogue_store(floatx4 (&acc)[NT][MT], const T* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) swap_rows16(v[r], v[4 + r]);
   };
-  // EPI_STATS: (sum, sum of squares) of the 32 stored values of row m in column part (nw0 + 32 np) / 32 -- eight in this lane, the
-  // other 24 in the lanes 16 / 32 / 48 away; the order below is the definition of a part's moments for every kernel
   auto emit_stats = [&](const float (&v)[8], int m, int np, bool ok) {
-    float a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    float q = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
-    a = add_xor16(a); q = add_xor16(q);
-    a = add_xor32(a); q = add_xor32(q);
-    if (g == 0 && ok) {
-      typedef float float2v __attribute__((ext_vector_type(2)));
-      *reinterpret_cast<float2v*>(ef->stats_out + (static_cast<size_t>(m) * (N >> 5) + ((nw0 + np * 32) >> 5)) * 2) = float2v{a, q};
-    }
+    part_stats_store(v, ef->stats_out, static_cast<size_t>(m), N, nw0 + np * 32, g, ok);
   };
   if (kInteriorOnly || (mw0 + MT * 16 <= M && nw0 + NT * 16 <= N)) {
     // interior wave tile (wave-uniform test): no clamps or predicates, one 64-bit row pointer per operand that

@@ -393,6 +393,18 @@ bool mx_linear_supported(int dtype, const MxLinearArgs& a) {
     if (a.act == ACT_GELU && (a.R1 || a.row_mask)) return false;
   }
   if (a.act != ACT_NONE && a.act != ACT_GELU) return false;
+  // the kernel is persistent and re-reads the block scales of its operands for every tile: nothing it writes may share bytes with
+  // them (or with the operand codes)
+  auto overlaps = [](const void* p, size_t np, const void* q, size_t nq) {
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(q);
+    return p && q && a0 < b0 + nq && b0 < a0 + np;
+  };
+  const size_t M = a.M, N = a.N, K = a.K, es = 2;
+  const struct { const void* p; size_t n; } ins[] = {{a.SX, M * (K / 32)}, {a.SW, N * (K / 32)}, {a.X8, (M - 1) * a.ldx + K}, {a.W8, N * K}};
+  const struct { const void* p; size_t n; } outs[] = {{a.Y8 ? nullptr : a.Y, ((M - 1) * a.ldy + N) * es}, {a.Y8, M * N}, {a.SY, M * (N / 32)}};
+  for (const auto& in : ins)
+    for (const auto& out : outs)
+      if (overlaps(in.p, in.n, out.p, out.n)) return false;
   return mx_geometry(a) != 0;
 }
 

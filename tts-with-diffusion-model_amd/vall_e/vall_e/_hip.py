@@ -49,7 +49,7 @@ class BlockWeights(C.Structure):
 
 class FoldBlock(C.Structure):
     """d3pm_fold_block: a block's LayerNorms folded into the projections they feed (filled by d3pm_fold_build)."""
-    _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "qkv_s", "qkv_b", "q2_w", "q2_s", "q2_b", "fc1_w", "fc1_s", "fc1_b")]
+    _fields_ = [(n, C.c_void_p) for n in ("qkv_w", "qkv_s", "qkv_b", "q2_w", "q2_s", "q2_b")]
 
 
 class Weights(C.Structure):
@@ -111,8 +111,7 @@ SIGNATURES = {
     "d3pm_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int]),
     "d3pm_film_table": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_void_p, C.c_void_p]),
     "d3pm_fold_bytes": (C.c_size_t, [C.POINTER(Shape)]),
-    "d3pm_fold_build": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FoldBlock),
-                                  C.c_void_p]),
+    "d3pm_fold_build": (C.c_int, [C.POINTER(Shape), C.POINTER(Weights), C.c_void_p, C.c_size_t, C.POINTER(FoldBlock), C.c_void_p]),
     "d3pm_op_row_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "d3pm_op_linear_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Tuning), C.c_void_p]),
@@ -320,16 +319,16 @@ class DeviceWeights:
                                 ptr("final.bias"), self.blocks, None)
         self.fold_blocks = self.fold_storage = None
 
-    def build_fold(self, shape: "Shape", film: torch.Tensor, device):
-        """The LayerNorm-folded projection tables (d3pm_fold_build): W o gamma per LayerNorm-fed projection, one fc1 copy per
-        (layer, timestep) for the FiLM modulation -- (timesteps + 1) x n_layers x 4 d^2 elements, 1.27 GB for the 100-step d = 512
-        model -- plus the fp32 column vectors.  Shapes that do not qualify (fp32, d_model not a multiple of 256) keep fold = NULL."""
+    def build_fold(self, shape: "Shape", device):
+        """The LayerNorm-folded projection tables (d3pm_fold_build): W o gamma for the QKV and the merged cross-attention query
+        projection of every block plus their fp32 column vectors (fc1's FiLM-folded copy depends on the timestep and is rebuilt
+        inside every denoiser evaluation).  Shapes that do not qualify (fp32, d_model not a multiple of 256) keep fold = NULL."""
         need = lib().d3pm_fold_bytes(C.byref(shape))
         if need == 0:
             return False
         self.fold_storage = torch.empty(need, dtype=torch.uint8, device=device)
         self.fold_blocks = (FoldBlock * shape.n_layers)()
-        check(lib().d3pm_fold_build(C.byref(shape), C.byref(self.c_struct), _p(film), _p(self.fold_storage), need, self.fold_blocks,
+        check(lib().d3pm_fold_build(C.byref(shape), C.byref(self.c_struct), _p(self.fold_storage), need, self.fold_blocks,
                                     stream_ptr()), "d3pm_fold_build")
         self.c_struct.fold = self.fold_blocks
         return True
@@ -437,7 +436,7 @@ class Sampler:
         check(lib().d3pm_film_table(C.byref(self.shape), C.byref(self.weights.c_struct), _p(self.film), stream_ptr()),
               "d3pm_film_table")
         # LayerNorm folded into the projections (include/d3pm_hip.h: d3pm_fold_block; tuning field ln_fold picks it per call)
-        self.folded = self.weights.build_fold(self.shape, self.film, self.device)
+        self.folded = self.weights.build_fold(self.shape, self.device)
 
     def fp8_weights(self) -> DeviceFp8Weights:
         """e4m3 weight copies for the fp8 fast path, quantised on first use."""
@@ -936,14 +935,21 @@ def set_workspace_alias(v: bool):
     TUNING.workspace_alias = 1 if v else 0
 
 
+_TUNING_VALUES = {"gemm_variant": (0, 2, 3, 4, 5, 6, 7, 8), "attn_query_groups": (0, 1, 2, 4, 32, 33), "lat_tile": (0, 1, 2, 3),
+                  "attn_pair_sequential": (0, 1, 2), "attn_cross_resident": (0, 1, 2, 3, 4, 5), "workspace_alias": (0, 1), "ln_fold": (0, 1)}
+
+
 @contextlib.contextmanager
 def tuning(**fields):
     """`with _hip.tuning(attn_query_groups=32, row_panel=0): ...` -- schedule choices for the calls made inside the block; the
     module's default Tuning is restored on exit, also when the body raises, so no test or caller can leak a schedule."""
     lib()
-    for name in fields:
+    for name, value in fields.items():
         if name not in TUNING_FIELDS:
             raise D3PMError(f"unknown tuning field {name!r}: one of {TUNING_FIELDS}")
+        ok = _TUNING_VALUES.get(name)
+        if ok is not None and int(value) not in ok and not (_is_ab and name == "attn_query_groups" and int(value) == 35):
+            raise D3PMError(f"{name} = {value}: not a shipped schedule (include/d3pm_hip.h)")
     saved = {name: getattr(TUNING, name) for name in fields}
     try:
         for name, value in fields.items():
