@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-nar", action="store_true", help="skip the extra NAR (levels 1..7) measurement")
     ap.add_argument("--no-nq8", action="store_true", help="skip the extra n_q = 8 extension measurement")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8 fast-path measurement (BASELINE.json configs[4])")
+    ap.add_argument("--no-vctk", action="store_true", help="skip the extra VCTK long-prompt measurement (BASELINE.json configs[3])")
     ap.add_argument("--streams", type=int, default=1, help="independent batch chunks on separate HIP streams")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket GEMM launches with HIP events (roofline.achieved is then 0): measures what the "
@@ -188,6 +189,67 @@ def fp8_fast_path(dev, dtype, batch, cfg, sd32, texts, proms):
                    "free-running id agreement compounds single near-tie flips over 49 iterations (teacher-forced agreement and "
                    "logits error: tests/test_gpu_parity.py::test_fp8_fast_path_agreement_with_the_16_bit_path)")
     return out
+
+
+def class_table(per_class, key):
+    """{class: launches, us per launch, TFLOP/s | GB/s, fraction of the roof that bounds it, share of the timed kernel time}
+    from d3pm_prof_read_class tuples (launches, ms, flops, bytes)."""
+    table = {}
+    for name, (n, ms, fl, by) in per_class.items():
+        if n == 0:
+            continue
+        sec = ms * 1e-3
+        row = {"launches_timed": n, "avg_launch_us": ms * 1e3 / n, "share_of_timed_kernel_time": None,
+               "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mb_per_launch": by / n / 1e6,
+               "tflops": fl / sec / 1e12 if sec > 0 else 0.0, "gbs": by / sec / 1e9 if sec > 0 else 0.0}
+        bound = "mfma" if name in ("gemm", "attention", "gemm_layernorm") and fl > 0 else "hbm"
+        if name == "gemm_layernorm":
+            bound = "hbm"      # 2 x 125 MB through HBM around 12.9 + 25.8 GFLOP per block: priced against both roofs
+            row["frac_of_mfma_peak"] = row["tflops"] / MFMA_PEAK_TFLOPS[key]
+        row["bound"] = bound
+        row["frac_of_bound"] = (row["tflops"] / MFMA_PEAK_TFLOPS[key]) if bound == "mfma" else (row["gbs"] / HBM_PEAK_GBS)
+        table[name] = row
+    total_ms = sum(v[1] for v in per_class.values())
+    for name, row in table.items():
+        row["share_of_timed_kernel_time"] = per_class[name][1] / total_ms if total_ms > 0 else None
+    return table
+
+
+CLASSES = (("gemm", 0), ("attention", 1), ("layernorm", 3), ("sample", 2), ("gemm_layernorm", 4))
+
+
+def vctk_long_prompt(dev, dtype, batch, key):
+    """BASELINE.json configs[3]: 10 s prompt (750 keys), 5 s target (375 frames on a 384 canvas),
+    200-step schedule (199 iterations), the same d = 512 model family.  Reported beside `value` (the headline stays configs[1]):
+    tokens/s of a batch, the p50 of one utterance, and the same per-class table as the headline."""
+    from vall_e.vall_e import AR, _hip, synth
+    cfg = synth.D3PMConfig.vctk_long_prompt()
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0))
+    m = m.to(dtype).to(dev)
+    texts, proms = synth.make_inputs(cfg, batch, 1)
+    texts, proms = [t.to(dev) for t in texts], [p.to(dev) for p in proms]
+    m.generate_audio(texts, proms, seed=1)
+    torch.cuda.synchronize()
+    reps, iters = 3, cfg.timesteps - 1
+    _hip.prof_enable(_hip.K_ALL, reps * (iters // 16 + 2) * (cfg.n_layers * 14 + 4) + 64)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        m.generate_audio(texts, proms, seed=2 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    per_class = {name: _hip.prof_read_class(k) for name, k in CLASSES}
+    _hip.prof_disable()
+    lat = []
+    for i in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        m.generate_audio(texts[:1], proms[:1], seed=i)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    return {"workload": f"vctk: {cfg_name(cfg)} S_text={cfg.s_text}, {batch} utterances", "seconds_per_batch": dt, "repetitions": reps,
+            "codec_tokens_per_s": batch * cfg.n_frames / dt, "p50_utterance_latency_ms": statistics.median(lat[1:]),
+            "whole_step_tflops": algorithmic_flops_per_step(cfg, batch) / dt / 1e12, "kernel_classes": class_table(per_class, key)}
 
 
 def host_cpu_info(cores):
@@ -476,9 +538,7 @@ def main():
         out = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    per_class = {name: _hip.prof_read_class(k) for name, k in (("gemm", _hip.K_GEMM), ("attention", _hip.K_ATTN),
-                                                                  ("layernorm", _hip.K_LN), ("sample", _hip.K_SAMPLE),
-                                                                  ("gemm_layernorm", _hip.K_GEMM_LN))}
+    per_class = {name: _hip.prof_read_class(k) for name, k in CLASSES}
     launches, gemm_ms, gemm_flops, gemm_bytes = per_class["gemm"]
     _hip.prof_disable()
     elapsed, ranks_seen = reduce_over_ranks(elapsed, world, dev if args.backend == "nccl" else torch.device("cpu"))
@@ -506,9 +566,10 @@ def main():
         key = args.dtype
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic("gemm") if args.config == "libritts" and batch == 32 else (None, "PMC passes cover the headline workload only")
-        result["roofline"] = {"bound": "mfma", "kernel": "gemm_mfma_* (the plain DiT projection / MLP / final GEMM launches inside the diffusion "
-                              "loop, incl. the self-attention out-projection: the largest class; the dual cross-attention out-projection fused "
-                              "with norm3 / FiLM is the gemm_layernorm row of kernel_classes)",
+        result["roofline"] = {"bound": "mfma", "kernel": "gemm_mfma_* (every projection / MLP / final GEMM launch inside the diffusion loop -- the "
+                              "largest class; with the LayerNorms folded into the projections (d3pm_tuning.ln_fold, the default) that is 37 launches "
+                              "per iteration and there is no stand-alone LayerNorm or row-panel launch left: the `layernorm` row of kernel_classes is "
+                              "the token-embedding gather and the per-iteration fc1 FiLM fold)",
                               "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[key], "unit": "TFLOP/s",
                               "frac": achieved / MFMA_PEAK_TFLOPS[key], "traffic": traffic,
                               "traffic_unit": "bytes/launch (L2 fabric-side, rocprofv3 PMC)", "traffic_source": traffic_src,
@@ -518,25 +579,9 @@ def main():
                               "launches_timed": launches, "avg_launch_us": gemm_ms * 1e3 / max(launches, 1),
                               "timing": "HIP event pairs on the launch stream around every launch of each 16th diffusion "
                                         "iteration of the timed region (bracketing all launches costs ~6 % of the step)"}
-        table = {}
-        for name, (n, ms, fl, by) in per_class.items():
-            if n == 0:
-                continue
-            sec = ms * 1e-3
-            row = {"launches_timed": n, "avg_launch_us": ms * 1e3 / n, "share_of_timed_kernel_time": None,
-                   "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mb_per_launch": by / n / 1e6,
-                   "tflops": fl / sec / 1e12 if sec > 0 else 0.0, "gbs": by / sec / 1e9 if sec > 0 else 0.0}
-            # gemm_layernorm: 2 x 125 MB through HBM around 12.9 + 25.8 GFLOP per block -- priced against both roofs below
-            bound = "mfma" if name in ("gemm", "attention") else "hbm"
-            row["bound"] = bound
-            row["frac_of_bound"] = (row["tflops"] / MFMA_PEAK_TFLOPS[key]) if bound == "mfma" else (row["gbs"] / HBM_PEAK_GBS)
-            if name == "gemm_layernorm":
-                row["frac_of_mfma_peak"] = row["tflops"] / MFMA_PEAK_TFLOPS[key]
-            table[name] = row
-        total_ms = sum(v[1] for v in per_class.values())
-        for name, row in table.items():
-            row["share_of_timed_kernel_time"] = per_class[name][1] / total_ms if total_ms > 0 else None
-        result["kernel_classes"] = table
+        result["kernel_classes"] = class_table(per_class, key)
+        result["launches_per_iteration"] = {name: round(v[0] / max(args.steps * len([t for t in range(iters, 0, -1) if t % 16 == 0]), 1), 2)
+                                            for name, v in per_class.items() if v[0]}
         whole = algorithmic_flops_per_step(cfg, batch) * iters / (cfg.timesteps - 1) / (ms_per_step * 1e-3) / 1e12
         result["whole_step_tflops"] = whole
         if not args.no_latency:
@@ -561,6 +606,9 @@ def main():
         if world == 1 and not args.no_fp8 and args.config == "libritts" and dtype != torch.float32:
             note("measuring the fp8 / 50-step fast path")
             result["fp8_fast_path"] = fp8_fast_path(dev, dtype, batch, cfg, sd32, texts, proms)
+        if world == 1 and not args.no_vctk and args.config == "libritts" and dtype != torch.float32:
+            note("measuring the VCTK long-prompt config")
+            result["vctk_long_prompt"] = vctk_long_prompt(dev, dtype, batch, args.dtype)
         if world == 1 and args.cpu_steps > 0:
             note("timing the CPU port of the reference sampler")
             cpu_texts, cpu_proms = synth.make_inputs(cfg, 1, 1)

@@ -432,9 +432,11 @@ int d3pm_op_linear_mx(int out_dtype, const void *X8, int ldx, const void *SX, co
                       void *Y, int ldy, const void *R1, int ldr, const uint8_t *row_mask, int mask_period, void *Y8, void *SY,
                       int M, int N, int K, int act, const d3pm_tuning *tuning, void *stream);
 /* The folded-LayerNorm pieces as single ops (MFMA family, 16-bit; d3pm_fold_block above):
- *   row_stats     stats[M][d / 32][2] = per row and 32-column part (sum x, sum x^2), fp32 -- what a producing projection leaves behind;
+ *   row_stats     per row and 32-column part the pair (sum x, sum x^2), fp32 -- what a producing projection leaves behind -- in the
+ *                 layout [ceil(M / 16)][d / 32][16][2] (the 16 rows of a row block side by side: one part of one row block is one
+ *                 128-byte line): the pair of (row, part) starts at float (((row / 16) * (d / 32) + part) * 16 + row % 16) * 2;
  *   linear_stats  d3pm_op_linear with a residual (R1 [+ R2] [+ row mask]) that also writes the moments of the rows it stores (N = d);
- *   linear_fold   Y = act(rstd_r (X_r . Wf^T - mean_r fold_s) + fold_b) with the moments of X's rows from `stats_in` [M][K / 32][2]
+ *   linear_fold   Y = act(rstd_r (X_r . Wf^T - mean_r fold_s) + fold_b) with the moments of X's rows from `stats_in` (layout of row_stats, K columns)
  *                 (X = the raw rows, Wf / fold_s / fold_b as d3pm_fold_build makes them); act 0 / 1 (GELU). */
 int d3pm_op_row_stats(int dtype, const void *X, int ldx, int M, int d, float *stats, void *stream);
 int d3pm_op_linear_stats(int dtype, const void *X, int ldx, const void *W, const void *bias, void *Y, int ldy, const void *R1,

@@ -58,7 +58,7 @@ def main():
         y = torch.empty(M, d, dtype=dt, device=DEV)
         for mode, fl in (("hot", None), ("cold", flush)):
             t_plain = timeit(lambda: _hip.op_linear(xx, w, b, r1=r1, out=y), flush=fl)
-            t_st = timeit(lambda: _hip.op_linear_stats(xx, w, b, r1), flush=fl)
+            t_st = timeit(lambda: _hip.op_linear_stats(xx, w, b, r1), flush=fl)      # allocates and zeroes its outputs: ~ +4 us of fill kernels
             print(f"{name:10s} {mode:5s} plain {t_plain:7.1f} us   +stats {t_st:7.1f} us", flush=True)
 
 

@@ -184,7 +184,7 @@ static Workspace carve(const d3pm_shape& sh, int batch, char* base) {
     w.mlp = take(n * 4 * d * es);
     w.logits = take(n * levels(sh) * logits_ld(sh) * es);
   }
-  w.stats = reinterpret_cast<float*>(take(n * ((d + 31) / 32) * 2 * sizeof(float)));
+  w.stats = reinterpret_cast<float*>(take(((n + 15) & ~static_cast<size_t>(15)) * ((d + 31) / 32) * 2 * sizeof(float)));
   w.mxs = reinterpret_cast<uint8_t*>(take(2 * n * ((d + 31) / 32)));
   if (fold_shape_ok(sh.dtype, sh.d_model)) {
     const size_t L = sh.n_layers;

@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void fold_rows_layers(FoldStepPtrs p, const T*
   }
 }
 
-// (sum, sum of squares) of every 32-column part of every row: stats[M][d / 32][2].  One wave per row, lane L of pass j owns the
+// float index of (row, part): [row / 16][part][row % 16][2] -- d3pm_mfma_tile.h has the same function for the GEMM epilogues
+__device__ __forceinline__ size_t stats_index(size_t row, int part, int parts) { return (((row >> 4) * parts + part) * 16 + (row & 15)) * 2; }
+
+// (sum, sum of squares) of every 32-column part of every row, in the layout above.  One wave per row, lane L of pass j owns the
 // 16-byte chunk 64 j + L; the four lanes of a quad own one part.  Used where the residual rows do not come out of a GEMM epilogue:
 // the token embedding in front of the first block (ar_discrete.py:753), and as a stand-alone op for tests.
 template <typename T>
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void row_stats(const T* __restrict__ x, int ld
     const Vec8<T> raw = *reinterpret_cast<const Vec8<T>*>(x + static_cast<size_t>(row) * ldx + c * 8);
     float a, q;
     part_moments(raw, a, q);
-    if ((lane & 3) == 0) *reinterpret_cast<float2v*>(stats + (static_cast<size_t>(row) * parts + (c >> 2)) * 2) = float2v{a, q};
+    if ((lane & 3) == 0) *reinterpret_cast<float2v*>(stats + stats_index(static_cast<size_t>(row), c >> 2, parts)) = float2v{a, q};
   }
 }
 
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void embed_rows_stats(const int32_t* __restric
     dst[c] = raw;
     float a, q;
     part_moments(raw, a, q);
-    if ((lane & 3) == 0) *reinterpret_cast<float2v*>(stats + (static_cast<size_t>(row) * parts + (c >> 2)) * 2) = float2v{a, q};
+    if ((lane & 3) == 0) *reinterpret_cast<float2v*>(stats + stats_index(static_cast<size_t>(row), c >> 2, parts)) = float2v{a, q};
   }
 }
 

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   // the top of the tile they stalled the second k-step instead (every k-step waits with vmcnt(0), vector-memory operations
   // retire in order).  The one place such a load can hide is ACROSS an epilogue: the moments of the NEXT row panel are requested
   // at the start of the epilogue of the last tile of this one, from inline asm (exactly 12 loads) behind the tile's own
-  // per-column vectors (8 asm loads), the epilogue waits with vmcnt(12) -- its vectors have landed, the moments may stay in
+  // per-column vectors (8 asm loads), the epilogue waits with vmcnt(24) -- its vectors have landed, the moments may stay in
   // flight -- and the next tile's first k-step, which waits for everything older than the 12 output stores anyway, finds them
   // landed; they are reduced to the two scalars per row right behind that k-step.  Together with the consecutive tile walk
   // (below) the folded launch is within 1-2 us of the plain one on cold operands (tests/ab_fold.py).
@@ -200,13 +200,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   const T* sw = W + static_cast<size_t>((tile % n_tiles) * TN) * K;
 #pragma unroll
   for (int p = 0; p < NDMA; ++p) dma(p, sx, sw, lds_base);          // first k-step of the first tile
-  [[maybe_unused]] floatx4 lst[6][2];                                // EPI_LNF: the moments of the tile about to start, in flight
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  [[maybe_unused]] float2v lst[6][4];                                // EPI_LNF: the moments of the tile about to start, in flight
   auto moments_request = [&](int mrow0) __attribute__((always_inline)) {
-    const float* sp = ef.stats_in + (static_cast<size_t>(mrow0 + wm * 96 + (lane & 15)) * 16 + (lane >> 4) * 4) * 2;
+    // parts 4 g .. 4 g + 3 of row (lane & 15) of each of the six 16-row blocks: [row block][part][row][2] (stats_index), 24 loads
+    const float* sp = ef.stats_in + stats_index(static_cast<size_t>(mrow0 + wm * 96 + (lane & 15)), (lane >> 4) * 4, 16);
 #pragma unroll
     for (int mt = 0; mt < 6; ++mt) {
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lst[mt][0]) : "v"(sp + mt * 16 * 32) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(lst[mt][1]) : "v"(sp + mt * 16 * 32) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(lst[mt][0]) : "v"(sp + mt * 512) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, off offset:128" : "=v"(lst[mt][1]) : "v"(sp + mt * 512) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, off offset:256" : "=v"(lst[mt][2]) : "v"(sp + mt * 512) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, off offset:384" : "=v"(lst[mt][3]) : "v"(sp + mt * 512) : "memory");
     }
   };
   if constexpr (kLnfPre) moments_request((tile / n_tiles) * TM);     // the first tile's: covered by the wait below
@@ -357,11 +361,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
         if (fresh)
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt) {
-          asm volatile("" : "+v"(lst[mt][0]), "+v"(lst[mt][1]));
-          const floatx4 p0 = lst[mt][0], p1 = lst[mt][1];
+          asm volatile("" : "+v"(lst[mt][0]), "+v"(lst[mt][1]), "+v"(lst[mt][2]), "+v"(lst[mt][3]));
           float a = 0.f, q = 0.f;
-          a += p0[0]; q += p0[1]; a += p0[2]; q += p0[3];
-          a += p1[0]; q += p1[1]; a += p1[2]; q += p1[3];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { a += lst[mt][i][0]; q += lst[mt][i][1]; }
           a = add_xor16(a); q = add_xor16(q);
           fold_row_scalars(add_xor32(a), add_xor32(q), 512, ef.eps, rows.ra[mt], rows.rc[mt]);
         }
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
         fresh = more && (tile_next / n_tiles) != (tile / n_tiles);      // the next tile reads other rows
         if (fresh) {
           moments_request((tile_next / n_tiles) * TM);
-          asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }

@@ -97,7 +97,9 @@ constexpr int EPI_GELU = 1, EPI_R1 = 2, EPI_R2 = 4, EPI_MASK = 8, EPI_RELU = 16,
 // so the projection that CONSUMES a LayerNorm reads the raw residual stream through the unchanged operand path and applies two
 // per-row scalars and two per-column vectors in its epilogue (EPI_LNF), and the projection that PRODUCES the residual rows
 // (out-projection / fc2 + residual) leaves their moments behind (EPI_STATS): per row and per 32-column part of the row the pair
-// (sum y, sum y^2) of the ROUNDED values it stores, fp32, no atomics -- stats[M][N / 32][2].  A part is what one 16-lane row group
+// (sum y, sum y^2) of the ROUNDED values it stores, fp32, no atomics.  Layout (stats_index): [M / 16][N / 32][16][2] -- the 16 rows
+// of an MFMA row block side by side, so that the store of one part by one wave is one whole 128-byte line (row-major it was 16
+// partial lines per store instruction and cost 2.5-3 us per producing launch).  A part is what one 16-lane row group
 // of any MFMA kernel's epilogue owns after the column regrouping (8 columns in each of 4 lanes), so every tile geometry sums a
 // part in the same order and writes the same bits; the consumer adds a row's parts in one fixed order (four lanes x parts_in / 4
 // parts each, then two butterfly steps).  var = E[y^2] - mean^2 in fp32: with |mean| <~ 10 sigma the relative error of rstd stays
@@ -112,6 +114,11 @@ struct EpiFold {
   int parts_in = 0;                  // K / 32, a multiple of 8
 };
 
+// float index of (row, part) in a moments buffer of `parts` parts per row: [row / 16][part][row % 16][2]
+__host__ __device__ __forceinline__ size_t stats_index(size_t row, int part, int parts) {
+  return (((row >> 4) * parts + part) * 16 + (row & 15)) * 2;
+}
+
 inline EpiFold epi_fold_of(const LinearArgs& a) {
   EpiFold e;
   e.s = a.fold_s; e.b = a.fold_b; e.stats_in = a.stats_in; e.stats_out = a.stats_out; e.eps = a.fold_eps; e.parts_in = a.K / 32;
@@ -121,13 +128,12 @@ inline EpiFold epi_fold_of(const LinearArgs& a) {
 // (sum, sum of squares) of row `row` from its parts: lane group g = lane >> 4 adds parts [g P / 4, (g + 1) P / 4) in order, then the
 // four groups are combined by two butterfly steps (a + b == b + a bit for bit, so all four lanes end with the same bits)
 __device__ __forceinline__ void fold_row_moments(const float* __restrict__ stats, int parts, size_t row, int g, float& s1, float& s2) {
+  typedef float float2v __attribute__((ext_vector_type(2)));
   const int per = parts >> 2;
-  const floatx4* p = reinterpret_cast<const floatx4*>(stats + (row * parts + static_cast<size_t>(g) * per) * 2);
   float a = 0.f, q = 0.f;
-  for (int i = 0; i < (per >> 1); ++i) {
-    const floatx4 v = p[i];
+  for (int i = 0; i < per; ++i) {
+    const float2v v = *reinterpret_cast<const float2v*>(stats + stats_index(row, g * per + i, parts));
     a += v[0]; q += v[1];
-    a += v[2]; q += v[3];
   }
   a = add_xor16(a); q = add_xor16(q);
   s1 = add_xor32(a); s2 = add_xor32(q);
@@ -153,7 +159,7 @@ __device__ __forceinline__ void part_stats_store(const float (&v)[8], float* __r
   float z = a + q, z2 = z;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(z), "+v"(z2));
   z += z2;
-  if (g < 2 && ok) stats_out[(m * (N >> 5) + (col0 >> 5)) * 2 + g] = z;
+  if (g < 2 && ok) stats_out[stats_index(m, col0 >> 5, N >> 5) + g] = z;
 }
 
 // per-row scalars of EPI_LNF computed ahead of the epilogue (big-tile GEMM: the moments are requested at the top of a tile and
@@ -216,10 +222,13 @@ __device__ __forceinline__ void epilogue_prefetch(EpiPre<T, NT, MT>& pre, const 
     if (ef->parts_in == 16) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        typedef float float2v __attribute__((ext_vector_type(2)));
         const int m = mw0 + mt * 16 + (lane & 15);
-        const floatx4* p = reinterpret_cast<const floatx4*>(ef->stats_in + (static_cast<size_t>(m < M ? m : M - 1) * 16 + g * 4) * 2);
-        pre.st[mt][0] = p[0];
-        pre.st[mt][1] = p[1];
+        const float* p = ef->stats_in + stats_index(static_cast<size_t>(m < M ? m : M - 1), g * 4, 16);      // parts 4g .. 4g + 3: 32 floats apart
+        const float2v p0 = *reinterpret_cast<const float2v*>(p), p1 = *reinterpret_cast<const float2v*>(p + 32),
+                      p2 = *reinterpret_cast<const float2v*>(p + 64), p3 = *reinterpret_cast<const float2v*>(p + 96);
+        pre.st[mt][0] = floatx4{p0[0], p0[1], p1[0], p1[1]};
+        pre.st[mt][1] = floatx4{p2[0], p2[1], p3[0], p3[1]};
       }
     }
   } else if (bias == nullptr) {

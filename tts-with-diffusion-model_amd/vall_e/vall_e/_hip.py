@@ -748,20 +748,30 @@ def op_attention_pair(q1, k1, v1, q2, k2, v2, n_heads, scale):
     return o1, o2
 
 
+def stats_buffer(M: int, parts: int, device) -> torch.Tensor:
+    """Storage of the row moments in the library's layout [ceil(M / 16), parts, 16, 2] (include/d3pm_hip.h: d3pm_op_row_stats)."""
+    return torch.zeros(((M + 15) // 16, parts, 16, 2), dtype=torch.float32, device=device)
+
+
+def stats_rows(st: torch.Tensor, M: int) -> torch.Tensor:
+    """The same moments as [M, parts, 2] (row-major view for tests)."""
+    return st.permute(0, 2, 1, 3).reshape(-1, st.shape[1], 2)[:M]
+
+
 def op_row_stats(x):
-    """[M, d] 16-bit rows -> fp32 [M, d // 32, 2] partial (sum, sum of squares) per 32-column part."""
+    """[M, d] 16-bit rows -> the fp32 partial (sum, sum of squares) per 32-column part, in the library's layout (stats_buffer)."""
     M, d = x.shape
-    st = torch.empty((M, d // 32, 2), dtype=torch.float32, device=x.device)
+    st = stats_buffer(M, d // 32, x.device)
     check(lib().d3pm_op_row_stats(dtype_code(x.dtype), _p(x), x.stride(0), M, d, _p(st), stream_ptr()), "d3pm_op_row_stats")
     return st
 
 
 def op_linear_stats(x, w, bias, r1, *, r2=None, row_mask=None, mask_period=1):
-    """(y, stats): y = residual epilogue of d3pm_op_linear, stats = the moments of the rows of y ([M, N // 32, 2])."""
+    """(y, stats): y = residual epilogue of d3pm_op_linear, stats = the moments of the rows of y (layout of stats_buffer)."""
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    st = torch.empty((M, N // 32, 2), dtype=torch.float32, device=x.device)
+    st = stats_buffer(M, N // 32, x.device)
     check(lib().d3pm_op_linear_stats(dtype_code(x.dtype), _p(x), x.stride(0), _p(w), _p(bias), _p(y), N, _p(r1), _p(r2), r1.stride(0),
                                      _p(row_mask), mask_period, M, N, K, _p(st), C.byref(TUNING), stream_ptr()), "d3pm_op_linear_stats")
     return y, st
