@@ -18,10 +18,11 @@ CLASSES = {"gemm": "gemm_mfma", "gemm_layernorm": "gemm_mfma_big", "gemm_mx": "g
 
 
 def fused_gemm(name):
-    """gemm_mfma_big<T, EPI, WM, WN, MODE, FUSE>: FUSE != 0 = the row-panel launches (projection + LayerNorms)."""
+    """gemm_mfma_big<T, EPI, WM, WN, MODE, FUSE>: FUSE with a LayerNorm bit = the row-panel launches (projection + LayerNorms);
+    FUSE = 1 alone is the dual out-projection on ordinary tiles (a plain GEMM launch)."""
     m = re.search(r"gemm_mfma_bigI\w+?Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EE", name)
     if m:
-        return int(m.group(5)) != 0
+        return (int(m.group(5)) & ~1) != 0
     m = re.search(r"gemm_mfma_big<([^>]*)>", name)
     if m:
         ints = re.findall(r"\b\d+\b", m.group(1))
@@ -38,6 +39,23 @@ def classify(name):
     return None
 
 
+# per-kernel rows beside the classes (which attention kernel re-fetches)
+KERNELS = {"attention_self_attn32p": "attn32p_hd64", "attention_cross_pair_attn32": "attn32_cross_hd64", "attention_self_16x16": "attn_mfma_hd64",
+           "gemm_folded_ln": None, "gemm_row_moments": None}
+
+
+def kernel_rows(name):
+    rows = [k for k, needle in KERNELS.items() if needle and needle in name]
+    m = re.search(r"gemm_mfma_bigI\w+?Li(\d+)E", name)
+    if m:
+        epi = int(m.group(1))
+        if epi & 64:
+            rows.append("gemm_folded_ln")
+        if epi & 128:
+            rows.append("gemm_row_moments")
+    return rows
+
+
 def load(directory, counter):
     import os
     path = max(glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
@@ -49,13 +67,16 @@ def load(directory, counter):
         if cls:
             agg[cls][0] += 1
             agg[cls][1] += float(r["Counter_Value"])
+        for k in kernel_rows(r["Kernel_Name"]):
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
     return agg
 
 
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     out = {}
-    for cls in CLASSES:
+    for cls in list(CLASSES) + list(KERNELS):
         if fetch[cls][0] == 0:
             continue
         f = fetch[cls][1] / fetch[cls][0] * 1024.0

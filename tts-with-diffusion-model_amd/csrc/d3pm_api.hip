@@ -125,8 +125,10 @@ static int run_row_panel(const Ctx& cx, int dtype, const LinearArgs& a, const Ro
 }
 static int run_attention(const Ctx& cx, int dtype, AttnArgs a, uint32_t flags, hipStream_t s) {
   a.tune = cx.tune;
+  // algorithmic bytes: queries in + outputs out (of BOTH problems of a paired launch: rounds 1-3 counted one, which made the
+  // pair look like 1.3x wasted traffic -- PMC says 118.8 MB against 118.6) + keys and values
   ProfScope p(cx, D3PM_K_ATTN, s, 4.0 * a.B * a.H * a.Tq * static_cast<double>(a.S + a.S2) * a.hd,
-              dtype_size(dtype) * (2.0 * a.B * a.Tq * a.H * a.hd + 2.0 * a.B * (a.S + a.S2) * a.H * a.hd));
+              dtype_size(dtype) * ((a.Q2 ? 4.0 : 2.0) * a.B * a.Tq * a.H * a.hd + 2.0 * a.B * (a.S + a.S2) * a.H * a.hd));
   if (!(flags & D3PM_FLAG_FORCE_GENERIC) && mfma_attention_supported(dtype, a)) return mfma_attention(dtype, a, s);
   if (a.Q2) {   // the generic kernel takes one problem per launch
     AttnArgs first = a, second = a;

@@ -143,7 +143,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   int t = blockIdx.x >> 3;
   // EPI_LNF: a workgroup walks CONSECUTIVE tiles -- n-tiles of one row panel (3 of the 12 of the qkv projection, 4 of fc1's 16) --
   // instead of every per_xcd-th one, so the row scalars of a panel are fetched and reduced once per workgroup, not once per tile
-  // (in the loop 102.2 k -> 103.4 k tokens/s; for the other epilogues the walk order measured no difference and stays as it was)
+  // (in the loop 102.2 k -> 103.4 k tokens/s; for the other epilogues the consecutive walk measured 0.5 % slower and they keep the
+  // strided one).  The walk re-reads a panel's X tile once per n-tile: that only pays because the output rows leave as `sc1`
+  // stores and do not push the panel out of L2 (PMC: 93.6 -> 49.1 MB fetched per folded launch, 104.5 k -> 110.5 k tokens/s)
   constexpr bool consec = kLnfPreDecl<EPI>;
   const int t_per = (cnt + per_xcd - 1) / per_xcd;
   const int t_end = consec ? ((t + 1) * t_per < cnt ? (t + 1) * t_per : cnt) : cnt, t_step = consec ? 1 : per_xcd;
@@ -437,7 +439,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
       const int g = lane >> 4, nq = epilogue_nq(lane);
       T* yrow = Y + static_cast<size_t>(m0 + wm * 96 + (lane & 15)) * ldy + n0 + wn * 64 + nq;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) *reinterpret_cast<uintx4*>(yrow + static_cast<size_t>((j / 2) * 16) * ldy + (j % 2) * 32) = xp[j];
+      for (int j = 0; j < 12; ++j) {
+        T* yp = yrow + static_cast<size_t>((j / 2) * 16) * ldy + (j % 2) * 32;
+        if constexpr (FUSE == FUSE_DUAL) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(yp), "v"(xp[j]) : "memory");   // as the plain epilogue (kNts)
+        else *reinterpret_cast<uintx4*>(yp) = xp[j];
+      }
       if constexpr ((EPI & EPI_STATS) != 0) {        // the row moments of the new rows for the folded LayerNorm that reads them next
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
@@ -622,11 +628,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
 #pragma unroll
           for (int r = 0; r < 4; ++r) { pre.bv[nt][r] = bq[nt][r]; pre.sv[nt][r] = sq[nt][r]; }
         }
-        epilogue_store<T, EPI, 4, 6, true, false, false, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
-                                                               n0 + wn * 64, lane, nullptr, gelu_tab, &pre, &ef, &rows);
+        epilogue_store<T, EPI, 4, 6, true, false, true, true>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
+                                                              n0 + wn * 64, lane, nullptr, gelu_tab, &pre, &ef, &rows);
       } else if (!kept)
-        epilogue_store<T, EPI, 4, 6, true, false, (MODE & 512) != 0, kPreEpi>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
-                                                                              n0 + wn * 64, lane, nullptr, gelu_tab, &pre, &ef);
+        // output rows leave as `sc1` stores (kNts): they are not read again by this launch, and left in the XCD's L2 they displace the
+        // operand panels the other tiles of the launch still stream (in the loop: 103.8 k -> 106.2 k tokens/s with the stand-alone
+        // LayerNorms, and what makes the folded launches' consecutive tile walk pay; MODE bit 9 used to try `nt`, which keeps the line)
+        epilogue_store<T, EPI, 4, 6, true, false, true, kPreEpi>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
+                                                                 n0 + wn * 64, lane, nullptr, gelu_tab, &pre, &ef);
     }
     if (!more) break;
     t = t_next;

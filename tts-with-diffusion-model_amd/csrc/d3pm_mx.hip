@@ -343,8 +343,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mx_big(const uint8_t* __
         }
       }
     } else {
-      epilogue_store<T, EPI, 4, 6, true, false>(acc, bias, Y, ldy, R1, nullptr, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
-                                                n0 + wn * 64, lane);
+      // `sc1` output stores, as in gemm_mfma_big: the rows are not read again by this launch and must not displace its operands in L2
+      epilogue_store<T, EPI, 4, 6, true, false, true>(acc, bias, Y, ldy, R1, nullptr, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
+                                                      n0 + wn * 64, lane);
     }
     if (!more) break;
     t = t_next;
