@@ -80,8 +80,6 @@ template <typename T> struct RowPanelArgs {
 };
 constexpr int FUSE_DUAL = 1, FUSE_LN = 2, FUSE_LN2 = 4, FUSE_FILM = 8, FUSE_ABL_NOLN = 16, FUSE_MX = 32;   // 16: timing-only (LayerNorm arithmetic skipped)
 
-template <int EPI> constexpr bool kLnfPreDecl = (EPI & EPI_LNF) != 0;
-
 template <typename T, int EPI, int WM, int WN, int MODE, int FUSE = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __restrict__ X, int ldx, const T* __restrict__ W,
                                                         const T* __restrict__ bias, T* Y, int ldy, const T* R1,
@@ -113,8 +111,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   // at the start of the epilogue of the last tile of this one, from inline asm (exactly 12 loads) behind the tile's own
   // per-column vectors (8 asm loads), the epilogue waits with vmcnt(24) -- its vectors have landed, the moments may stay in
   // flight -- and the next tile's first k-step, which waits for everything older than the 12 output stores anyway, finds them
-  // landed; they are reduced to the two scalars per row right behind that k-step.  Together with the consecutive tile walk
-  // (below) the folded launch is within 1-2 us of the plain one on cold operands (tests/ab_fold.py).
+  // landed; they are reduced to the two scalars per row right behind that k-step.
   constexpr bool kLnfPre = (EPI & EPI_LNF) != 0;
   constexpr int NPRE = !kPreEpi ? 0 : ((EPI & EPI_R1) ? 12 : 0) + ((EPI & EPI_MASK) ? 6 : 0);
   static_assert((MODE & 32768) == 0 || (!kDrip && (MODE & 1)), "epilogue prefetch rides in the hand-placed schedule");
@@ -141,15 +138,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
   const int tq = tiles_total >> 3, tr = tiles_total & 7;
   const int lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, cnt = tq + (xcd < tr ? 1 : 0);
   int t = blockIdx.x >> 3;
-  // EPI_LNF: a workgroup walks CONSECUTIVE tiles -- n-tiles of one row panel (3 of the 12 of the qkv projection, 4 of fc1's 16) --
-  // instead of every per_xcd-th one, so the row scalars of a panel are fetched and reduced once per workgroup, not once per tile
-  // (in the loop 102.2 k -> 103.4 k tokens/s; for the other epilogues the consecutive walk measured 0.5 % slower and they keep the
-  // strided one).  The walk re-reads a panel's X tile once per n-tile: that only pays because the output rows leave as `sc1`
-  // stores and do not push the panel out of L2 (PMC: 93.6 -> 49.1 MB fetched per folded launch, 104.5 k -> 110.5 k tokens/s)
-  constexpr bool consec = kLnfPreDecl<EPI>;
-  const int t_per = (cnt + per_xcd - 1) / per_xcd;
-  const int t_end = consec ? ((t + 1) * t_per < cnt ? (t + 1) * t_per : cnt) : cnt, t_step = consec ? 1 : per_xcd;
-  if (consec) t *= t_per;
+  // Tile walk: workgroup slot s of an XCD takes tiles s, s + per_xcd, .. of the XCD's range, so the n-tiles of one row panel run at
+  // the same time on neighbouring CUs and share the panel's X rows in L2 (fetched from the fabric once).  A walk over CONSECUTIVE
+  // tiles (one workgroup = 3-4 n-tiles of one panel, its row scalars fetched once) was measured for the folded launches: +1.2 %
+  // while the output rows still went through L2, nothing once they left as `sc1` stores (106.8 k vs 106.7 k tokens/s) -- and it
+  // re-fetched each panel 2-3 times from the fabric (PMC 93.6 MB per launch against 49 / 30 algorithmic), so it is not kept.
+  const int t_end = cnt, t_step = per_xcd;
   if (t >= t_end) return;                                            // block-uniform
   if constexpr ((MODE & (8192 | 16384)) != 0) {
     // A/B: de-synchronise the chip-wide output burst -- the workgroups of every second XCD start later by a fraction of a tile
@@ -633,7 +627,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_mfma_big(const T* __rest
       } else if (!kept)
         // output rows leave as `sc1` stores (kNts): they are not read again by this launch, and left in the XCD's L2 they displace the
         // operand panels the other tiles of the launch still stream (in the loop: 103.8 k -> 106.2 k tokens/s with the stand-alone
-        // LayerNorms, and what makes the folded launches' consecutive tile walk pay; MODE bit 9 used to try `nt`, which keeps the line)
+        // LayerNorms, 104.5 k -> 110.5 k with them folded; MODE bit 9 of the A/B library used to try `nt`, which keeps the line in L2)
         epilogue_store<T, EPI, 4, 6, true, false, true, kPreEpi>(acc, bias, Y, ldy, R1, R2, ldr, row_mask, mask_period, M, N, m0 + wm * 96,
                                                                  n0 + wn * 64, lane, nullptr, gelu_tab, &pre, &ef);
     }
