@@ -586,12 +586,15 @@ def main():
         result["whole_step_tflops"] = whole
         if not args.no_latency:
             note(f"timed region {elapsed:.2f}s; measuring single-utterance latency")
-            for key, use_graph in (("p50_utterance_latency_ms", False), ("p50_utterance_latency_graph_replay_ms", True)):
+            # third form: one utterance run as a shard of a 32-utterance logical batch (global_batch = 32: it takes the 32 x 32 x 16
+            # attention kernels of the big batch, so that its ids are those of the unsplit batch) -- what rank-count independence costs
+            for key, use_graph, gb in (("p50_utterance_latency_ms", False, None), ("p50_utterance_latency_graph_replay_ms", True, None),
+                                       ("p50_utterance_latency_as_shard_of_32_ms", False, 32)):
                 lat = []
                 for i in range(6):       # the first two calls of the graph mode warm up and capture
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    model.generate_audio(texts[:1], proms[:1], seed=i, graph=use_graph)
+                    model.generate_audio(texts[:1], proms[:1], seed=i, graph=use_graph, global_batch=gb)
                     torch.cuda.synchronize()
                     lat.append((time.perf_counter() - t1) * 1e3)
                 result[key] = statistics.median(lat[2:])
