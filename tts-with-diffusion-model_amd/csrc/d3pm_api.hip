@@ -224,7 +224,7 @@ static char* at(void* p, size_t elems, size_t es) { return static_cast<char*>(p)
 //   fc1 + GELU <- x [norm3 + FiLM(t) folded], fc2 + x, frame mask (+ moments) }: ten launches per block, none of them a LayerNorm.
 static int denoiser_blocks_folded(const d3pm_shape& sh, const d3pm_weights& w, int batch, const int32_t* x_t, const uint8_t* frame_mask,
                                   int t, const void* film, const void* kv_text, const void* kv_prompt, const Workspace& ws, int layers,
-                                  hipStream_t s) {
+                                  hipStream_t s, bool prepared) {
   const int dt = sh.dtype, d = sh.d_model, H = sh.n_heads, hd = d / H, T = sh.canvas, n = batch * T;
   const Ctx cx(sh.tuning);
   const size_t es = dtype_size(dt);
@@ -232,14 +232,16 @@ static int denoiser_blocks_folded(const d3pm_shape& sh, const d3pm_weights& w, i
   EmbedArgs e;
   e.tokens = x_t; e.frame_mask = frame_mask; e.canvas = T; e.table = w.resps_emb; e.Y = ws.x;
   e.M = n; e.d = d; e.n_classes = sh.n_classes; e.n_q = levels(sh);
-  {
-    ProfScope p(cx, D3PM_K_LN, s, 0.0, es * static_cast<double>(n) * d * 2.0);
-    D3PM_TRY(embed_tokens_stats(dt, e, ws.stats, s));
-  }
-  {   // fc1 of every block under norm3 + FiLM(t): the weights this evaluation's fc1 launches read
-    ProfScope p(cx, D3PM_K_LN, s, 0.0, es * 2.0 * layers * 4.0 * d * d);
-    D3PM_TRY(fold_fc1_step_launch(dt, w.blocks, layers, at(film, static_cast<size_t>(t) * sh.n_layers * 2 * d, es), d, ws.fc1f, ws.fc1f_s,
-                                  ws.fc1f_b, s));
+  if (!prepared) {      // (inside the loop the previous iteration's sampler launch has done both: posterior_sample_prep)
+    {
+      ProfScope p(cx, D3PM_K_LN, s, 0.0, es * static_cast<double>(n) * d * 2.0);
+      D3PM_TRY(embed_tokens_stats(dt, e, ws.stats, s));
+    }
+    {   // fc1 of every block under norm3 + FiLM(t): the weights this evaluation's fc1 launches read
+      ProfScope p(cx, D3PM_K_LN, s, 0.0, es * 2.0 * layers * 4.0 * d * d);
+      D3PM_TRY(fold_fc1_step_launch(dt, w.blocks, layers, at(film, static_cast<size_t>(t) * sh.n_layers * 2 * d, es), d, ws.fc1f, ws.fc1f_s,
+                                    ws.fc1f_b, s));
+    }
   }
   auto folded = [&](const void* Wf, const float* fs, const float* fb, void* Y, int N, int act) -> int {
     LinearArgs g;
@@ -304,10 +306,15 @@ static int denoiser_blocks_folded(const d3pm_shape& sh, const d3pm_weights& w, i
 }
 
 // hidden state after `layers` blocks is left in ws.x
+// is this evaluation taking the folded-LayerNorm launch sequence (denoiser_blocks_folded)?
+static bool fold_active(const d3pm_shape& sh, const d3pm_weights& w, uint32_t flags, const d3pm_fp8_block_weights* f8) {
+  return !f8 && w.fold && tune_of(sh.tuning).ln_fold && !(flags & D3PM_FLAG_FORCE_GENERIC) && fold_shape_ok(sh.dtype, sh.d_model);
+}
+
 static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batch, const int32_t* x_t,
                            const uint8_t* frame_mask, int t, const void* film, const void* kv_text,
                            const void* kv_prompt, const Workspace& ws, int layers, uint32_t flags, hipStream_t s,
-                           const d3pm_fp8_block_weights* f8 = nullptr) {
+                           const d3pm_fp8_block_weights* f8 = nullptr, bool prepared = false) {
   const int dt = sh.dtype, d = sh.d_model, H = sh.n_heads, hd = d / H, T = sh.canvas;
   const int n = batch * T;
   const Ctx cx(sh.tuning);
@@ -343,8 +350,8 @@ static int denoiser_blocks(const d3pm_shape& sh, const d3pm_weights& w, int batc
 
   // LayerNorm folded into the projections (d3pm_tuning.ln_fold, d3pm_fold_block): every LayerNorm-fed projection reads the raw
   // residual stream and normalises in its epilogue; every projection that lands on the residual stream leaves the row moments
-  if (!use8 && w.fold && tune_of(sh.tuning).ln_fold && !(flags & D3PM_FLAG_FORCE_GENERIC) && fold_shape_ok(dt, d))
-    return denoiser_blocks_folded(sh, w, batch, x_t, frame_mask, t, film, kv_text, kv_prompt, ws, layers, s);
+  if (fold_active(sh, w, flags, f8))
+    return denoiser_blocks_folded(sh, w, batch, x_t, frame_mask, t, film, kv_text, kv_prompt, ws, layers, s, prepared);
 
   EmbedArgs e;
   e.tokens = x_t; e.frame_mask = frame_mask; e.canvas = T; e.table = w.resps_emb; e.Y = ws.x;
@@ -859,9 +866,11 @@ static int sample_loop_impl(const d3pm_shape* sh, const d3pm_weights* w, int bat
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int rows = batch * sh->canvas;
   const Ctx cx(sh->tuning);
+  bool prepared = false;      // the previous iteration's sampler launch has already embedded x_t and folded fc1 for this t
   for (int t = t_start; t > t_stop; --t) {
     if (cx.prof) cx.prof->sample_now = (t % cx.prof->stride) == 0;
-    D3PM_TRY(denoiser_blocks(*sh, *w, batch, x, frame_mask, t, film, kv_text, kv_prompt, ws, sh->n_layers, flags, s, f8));
+    D3PM_TRY(denoiser_blocks(*sh, *w, batch, x, frame_mask, t, film, kv_text, kv_prompt, ws, sh->n_layers, flags, s, f8, prepared));
+    prepared = false;
     SampleArgs a;
     a.logits = ws.logits; a.logits_dtype = sh->dtype; a.ldl = logits_ld(*sh); a.x_t = x; a.x_next = x;
     a.x_next2 = trace ? trace + static_cast<size_t>(t_start - t) * rows * levels(*sh) : nullptr;
@@ -883,7 +892,20 @@ static int sample_loop_impl(const d3pm_shape* sh, const d3pm_weights* w, int bat
       D3PM_TRY(final_logits(*sh, *w, batch, ws, ws.logits, logits_ld(*sh), flags, s));
       ProfScope p(cx, D3PM_K_SAMPLE, s, 0.0,
                   static_cast<double>(rows) * levels(*sh) * (sh->n_classes * dtype_size(sh->dtype) + 8.0));
-      D3PM_TRY(posterior_sample(a, s));
+      NextIterPrep nx;
+      if (t - 1 > t_stop && fold_active(*sh, *w, flags, f8)) {
+        const size_t es = dtype_size(sh->dtype);
+        nx.dtype = sh->dtype; nx.table = w->resps_emb; nx.x = ws.x; nx.stats = ws.stats; nx.frame_mask = frame_mask; nx.d = sh->d_model;
+        nx.blocks = w->blocks; nx.n_layers = sh->n_layers;
+        nx.film_t = at(film, static_cast<size_t>(t - 1) * sh->n_layers * 2 * sh->d_model, es);
+        nx.Wf = ws.fc1f; nx.s_out = ws.fc1f_s; nx.b_out = ws.fc1f_b;
+      }
+      if (nx.table && posterior_sample_prep_supported(a, nx)) {
+        D3PM_TRY(posterior_sample_prep(a, nx, s));       // + the embedding rows, their moments and the fc1 fold of iteration t - 1
+        prepared = true;
+      } else {
+        D3PM_TRY(posterior_sample(a, s));
+      }
     }
   }
   if (cx.prof) cx.prof->sample_now = false;

@@ -12,11 +12,10 @@
 // W' is rounded to the storage type once; s is summed over the ROUNDED W' (so that x . W' - mean s cancels exactly what the matrix
 // pipe accumulated), b' over the unrounded products, both in fp32.
 #include "d3pm_kernels.h"
+#include "d3pm_fold_rows.h"
 
 namespace d3pm {
 namespace {
-
-template <typename T> struct Vec8 { T v[8]; };
 
 // one wave per output row (t, n): W row n [K], gamma / beta [K], optional FiLM row film + t * film_ld = (scale [K] | shift [K])
 template <typename T>
@@ -59,68 +58,19 @@ __global__ __launch_bounds__(256) void fold_rows(const T* __restrict__ W, const 
   }
 }
 
-// fc1 of every layer at one timestep, one launch: row r = (layer r / n_rows, output n = r % n_rows); film_t = film[t] = [L][2K]
-struct FoldStepPtrs { const void* W[16]; const void* bias[16]; const void* gamma[16]; const void* beta[16]; };
+// fc1 of every layer at one timestep, one launch (d3pm_fold_rows.h)
 template <typename T>
 __global__ __launch_bounds__(256) void fold_rows_layers(FoldStepPtrs p, const T* __restrict__ film_t, int n_rows, int n_layers, int K,
                                                         T* __restrict__ Wf, float* __restrict__ s_out, float* __restrict__ b_out) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
   if (r >= n_rows * n_layers) return;
-  const int l = r / n_rows, n = r % n_rows;
-  const T* wrow = static_cast<const T*>(p.W[l]) + static_cast<size_t>(n) * K;
-  const T* gamma = static_cast<const T*>(p.gamma[l]);
-  const T* beta = static_cast<const T*>(p.beta[l]);
-  const T* frow = film_t + static_cast<size_t>(l) * 2 * K;
-  T* orow = Wf + static_cast<size_t>(r) * K;
-  float s = 0.f, b = 0.f;
-  for (int k = lane * 8; k < K; k += 512) {
-    const Vec8<T> w8 = *reinterpret_cast<const Vec8<T>*>(wrow + k), g8 = *reinterpret_cast<const Vec8<T>*>(gamma + k),
-                  b8 = *reinterpret_cast<const Vec8<T>*>(beta + k), sc8 = *reinterpret_cast<const Vec8<T>*>(frow + k),
-                  sh8 = *reinterpret_cast<const Vec8<T>*>(frow + K + k);
-    Vec8<T> o8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {          // the arithmetic of fold_rows with FiLM, statement for statement
-      const float w = static_cast<float>(w8.v[i]);
-      float g = static_cast<float>(g8.v[i]), c = static_cast<float>(b8.v[i]);
-      const float gg = rn<T>(1.0f + static_cast<float>(sc8.v[i]));
-      g *= gg;
-      c = __builtin_fmaf(c, gg, static_cast<float>(sh8.v[i]));
-      o8.v[i] = static_cast<T>(w * g);
-      s += static_cast<float>(o8.v[i]);
-      b = __builtin_fmaf(w, c, b);
-    }
-    *reinterpret_cast<Vec8<T>*>(orow + k) = o8;
-  }
-  s = wave_sum(s);
-  b = wave_sum(b);
-  if (lane == 0) {
-    s_out[r] = s;
-    b_out[r] = b + static_cast<float>(static_cast<const T*>(p.bias[l])[n]);
-  }
+  fold_layer_row<T>(p, film_t, n_rows, K, r, lane, Wf, s_out, b_out);
 }
 
-// float index of (row, part): [row / 16][part][row % 16][2] -- d3pm_mfma_tile.h has the same function for the GEMM epilogues
-__device__ __forceinline__ size_t stats_index(size_t row, int part, int parts) { return (((row >> 4) * parts + part) * 16 + (row & 15)) * 2; }
-
-// (sum, sum of squares) of every 32-column part of every row, in the layout above.  One wave per row, lane L of pass j owns the
-// 16-byte chunk 64 j + L; the four lanes of a quad own one part.  Used where the residual rows do not come out of a GEMM epilogue:
-// the token embedding in front of the first block (ar_discrete.py:753), and as a stand-alone op for tests.
-template <typename T>
-__device__ __forceinline__ void part_moments(const Vec8<T>& raw, float& a, float& q) {
-  float v[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(raw.v[i]);
-  a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));      // = part_moments8 of d3pm_mfma_tile.h
-  q = v[7] * v[7];
-#pragma unroll
-  for (int i = 6; i >= 0; --i) q = __builtin_fmaf(v[i], v[i], q);
-  // the order of the GEMM epilogues (d3pm_mfma_tile.h emit_stats: columns 0-7 + 16-23, then + (8-15 + 24-31)), so that the moments
-  // of a row are the same bits whichever kernel produced them
-  a = add_dpp<0x4E>(a); q = add_dpp<0x4E>(q);     // lane ^ 2
-  a = add_dpp<0xB1>(a); q = add_dpp<0xB1>(q);     // lane ^ 1
-}
-
+// (sum, sum of squares) of every 32-column part of every row, in the layout of d3pm_mfma_tile.h stats_index.  One wave per row,
+// lane L of pass j owns the 16-byte chunk 64 j + L; the four lanes of a quad own one part.  Used where the residual rows do not
+// come out of a GEMM epilogue: the token embedding in front of the first block (ar_discrete.py:753), and as a stand-alone op.
 template <typename T>
 __global__ __launch_bounds__(256) void row_stats(const T* __restrict__ x, int ldx, int M, int d, float* __restrict__ stats) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -132,7 +82,7 @@ __global__ __launch_bounds__(256) void row_stats(const T* __restrict__ x, int ld
     const Vec8<T> raw = *reinterpret_cast<const Vec8<T>*>(x + static_cast<size_t>(row) * ldx + c * 8);
     float a, q;
     part_moments(raw, a, q);
-    if ((lane & 3) == 0) *reinterpret_cast<float2v*>(stats + stats_index(static_cast<size_t>(row), c >> 2, parts)) = float2v{a, q};
+    if ((lane & 3) == 0) *reinterpret_cast<float2v*>(stats + stats_index_dev(static_cast<size_t>(row), c >> 2, parts)) = float2v{a, q};
   }
 }
 
@@ -144,21 +94,7 @@ __global__ __launch_bounds__(256) void embed_rows_stats(const int32_t* __restric
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
-  typedef float float2v __attribute__((ext_vector_type(2)));
-  int id = tok[row];
-  id = id < 0 ? 0 : (id >= n_classes ? n_classes - 1 : id);
-  const bool live = frame_mask[row % canvas] != 0;
-  const Vec8<T>* src = reinterpret_cast<const Vec8<T>*>(table + static_cast<size_t>(id) * d);
-  Vec8<T>* dst = reinterpret_cast<Vec8<T>*>(y + static_cast<size_t>(row) * d);
-  const int parts = d >> 5;
-  for (int c = lane; c < (d >> 3); c += kWave) {
-    Vec8<T> raw = src[c];
-    if (!live) raw = Vec8<T>{};
-    dst[c] = raw;
-    float a, q;
-    part_moments(raw, a, q);
-    if ((lane & 3) == 0) *reinterpret_cast<float2v*>(stats + stats_index(static_cast<size_t>(row), c >> 2, parts)) = float2v{a, q};
-  }
+  embed_row_stats<T>(table, tok[row], frame_mask[row % canvas] != 0, y, row, d, n_classes, stats, lane);
 }
 
 }  // namespace

@@ -148,6 +148,17 @@ int cond_embed_text(int dtype, const int32_t* tok, const void* table, const void
 int cond_embed_prompt(int dtype, const int32_t* codes, int n_levels, const void* tables, const void* pe, void* y,
                       int rows, int s_prompt, int d, int n_classes, hipStream_t s);
 int posterior_sample(const SampleArgs& a, hipStream_t s);
+// What the sampler launch of iteration t can prepare for iteration t - 1 (folded-LayerNorm path, n_q = 1; d3pm_sample.hip): the
+// embedding row of every id it has just drawn + the row's moments (ar_discrete.py:753,127), and -- in workgroups behind the
+// sampler's -- fc1 of every block under norm3 + FiLM(t - 1) (:145-159).  Two launches less per iteration, same bits.
+struct NextIterPrep {
+  int dtype = D3PM_BF16;
+  const void* table = nullptr; void* x = nullptr; float* stats = nullptr; const uint8_t* frame_mask = nullptr; int d = 0;
+  const d3pm_block_weights* blocks = nullptr; int n_layers = 0; const void* film_t = nullptr;      // film_t: row t - 1 of the FiLM table
+  void* Wf = nullptr; float* s_out = nullptr; float* b_out = nullptr;
+};
+bool posterior_sample_prep_supported(const SampleArgs& a, const NextIterPrep& n);
+int posterior_sample_prep(const SampleArgs& a, const NextIterPrep& n, hipStream_t s);
 
 // fp8 fast path on the block-scaled MFMA (d3pm_mx.hip): e4m3 codes [rows][K] + e8m0 block scales [rows][4][K / 128]
 //   Y[M][N] = epilogue(sum_k X8 2^sx . W8 2^sw + bias), epilogue as LinearArgs (plain, GELU, R1, R1 + mask); with Y8 / SY set the

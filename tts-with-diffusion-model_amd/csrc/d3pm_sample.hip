@@ -20,6 +20,7 @@
 #include <cmath>
 
 #include "d3pm_kernels.h"
+#include "d3pm_fold_rows.h"
 #include "d3pm_sample_row.h"
 
 namespace d3pm {
@@ -45,6 +46,35 @@ __global__ __launch_bounds__(256) void posterior_sample_rows(
     x_next[row] = best_j;
     if (x_next2) x_next2[row] = best_j;
   }
+}
+
+// The sampler of iteration t and the preparation of iteration t - 1 in one launch (NextIterPrep, d3pm_kernels.h): workgroups
+// [0, sample_blocks) draw x_{t-1} for four rows each and at once gather those rows' embeddings into the residual stream with
+// their moments (the id is in every lane after the wave argmax); the workgroups behind them rebuild fc1 o norm3 o FiLM(t - 1) of
+// every block.  The two halves are independent (one VALU-bound, one a 24-MB stream), so the launch costs the longer of them: at one
+// utterance 12.4 + 8.7 + 5.0 us of launches become ~13, at 32 utterances 94 + 10.8 + 10.5 become ~97.
+template <typename T>
+__global__ __launch_bounds__(256) void posterior_sample_prep_rows(
+    const T* __restrict__ logits, int ldl, const int32_t* x_t, int32_t* x_next, int32_t* x_next2, int rows, int K, int mask_id,
+    uint64_t seed, const uint64_t* __restrict__ seed_hbm, uint32_t row0, int greedy, PosteriorConsts pc, int canvas, int sample_blocks,
+    const T* __restrict__ table, T* __restrict__ xres, float* __restrict__ stats, const uint8_t* __restrict__ frame_mask, int d,
+    FoldStepPtrs fp, const T* __restrict__ film_t, int n_layers, T* __restrict__ Wf, float* __restrict__ s_out, float* __restrict__ b_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (static_cast<int>(blockIdx.x) >= sample_blocks) {
+    const int r = (blockIdx.x - sample_blocks) * 4 + wave;
+    if (r < 4 * d * n_layers) fold_layer_row<T>(fp, film_t, 4 * d, d, r, lane, Wf, s_out, b_out);
+    return;
+  }
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  if (seed_hbm) seed = *seed_hbm;
+  const int best_j = sample_row<T>(logits + static_cast<size_t>(row) * ldl, K, mask_id, x_t[row], seed, row0 + static_cast<uint32_t>(row), greedy, pc,
+                                   nullptr, lane, 0u);
+  if (lane == 0) {
+    x_next[row] = best_j;
+    if (x_next2) x_next2[row] = best_j;
+  }
+  embed_row_stats<T>(table, best_j, frame_mask[row % canvas] != 0, xres, row, d, K, stats, lane);
 }
 
 // forward noising: logits are log16(rn16(row_of_Qbar_t + eps)) with at most three distinct values
@@ -112,6 +142,28 @@ int posterior_sample(const SampleArgs& a, hipStream_t s) {
     default: set_error("unknown logits dtype %d", a.logits_dtype); return D3PM_E_ARG;
   }
 #undef D3PM_PS
+  D3PM_LAUNCH_CHECK();
+  return D3PM_OK;
+}
+
+bool posterior_sample_prep_supported(const SampleArgs& a, const NextIterPrep& n) {
+  return a.n_q == 1 && !a.posterior_out && a.logits_dtype == n.dtype && (n.dtype == D3PM_F16 || n.dtype == D3PM_BF16) && n.n_layers <= 16 &&
+         n.d % 256 == 0 && a.n_classes <= kWave * kMaxGroupsPerLane * 4 && n.table && n.x && n.stats && n.blocks && n.film_t && n.Wf;
+}
+
+int posterior_sample_prep(const SampleArgs& a, const NextIterPrep& n, hipStream_t s) {
+  FoldStepPtrs p{};
+  for (int l = 0; l < n.n_layers; ++l) {
+    p.W[l] = n.blocks[l].fc1_w; p.bias[l] = n.blocks[l].fc1_b; p.gamma[l] = n.blocks[l].norm3_w; p.beta[l] = n.blocks[l].norm3_b;
+  }
+  const int sample_blocks = (a.rows + 3) / 4, fold_blocks = (4 * n.d * n.n_layers + 3) / 4;
+  const dim3 grid(static_cast<unsigned>(sample_blocks + fold_blocks)), block(256);
+#define D3PM_PSP(T)                                                                                                                 \
+  posterior_sample_prep_rows<T><<<grid, block, 0, s>>>(static_cast<const T*>(a.logits), a.ldl, a.x_t, a.x_next, a.x_next2, a.rows, a.n_classes, \
+      a.mask_id, a.seed, a.seed_hbm, a.row0, a.greedy, a.pc, a.canvas, sample_blocks, static_cast<const T*>(n.table), static_cast<T*>(n.x),    \
+      n.stats, n.frame_mask, n.d, p, static_cast<const T*>(n.film_t), n.n_layers, static_cast<T*>(n.Wf), n.s_out, n.b_out)
+  if (n.dtype == D3PM_F16) D3PM_PSP(f16); else D3PM_PSP(bf16);
+#undef D3PM_PSP
   D3PM_LAUNCH_CHECK();
   return D3PM_OK;
 }
