@@ -38,10 +38,13 @@ __global__ __launch_bounds__(256) void posterior_sample_rows(
   // n_q > 1 (d3pm_shape.n_q): row = frame row * n_q + level; the level-0 token of a frame draws the noise the level-0-only
   // path draws, level l > 0 draws from Philox stream 16 + l at the same (frame row, t)
   const int frow = n_q > 1 ? row / n_q : row, level = row - frow * (n_q > 1 ? n_q : 1);
-  const int best_j = sample_row<T>(logits + static_cast<size_t>(row) * ldl, K, mask_id, x_t[row], seed,
-                                   row0 + static_cast<uint32_t>(frow), greedy, pc,
-                                   post_out ? post_out + static_cast<size_t>(row) * K : nullptr, lane,
-                                   level ? 16u + static_cast<uint32_t>(level) : 0u);
+  const uint32_t strm = level ? 16u + static_cast<uint32_t>(level) : 0u;
+  int best_j;
+  if (K == 1025 && mask_id < 1024 && !post_out)        // kernel-uniform: the predicate-free routine for the reference's class count (same bits)
+    best_j = sample_row_1025<T>(logits + static_cast<size_t>(row) * ldl, mask_id, x_t[row], seed, row0 + static_cast<uint32_t>(frow), greedy, pc, lane, strm);
+  else
+    best_j = sample_row<T>(logits + static_cast<size_t>(row) * ldl, K, mask_id, x_t[row], seed, row0 + static_cast<uint32_t>(frow), greedy, pc,
+                           post_out ? post_out + static_cast<size_t>(row) * K : nullptr, lane, strm);
   if (lane == 0) {
     x_next[row] = best_j;
     if (x_next2) x_next2[row] = best_j;
@@ -68,8 +71,9 @@ __global__ __launch_bounds__(256) void posterior_sample_prep_rows(
   const int row = blockIdx.x * 4 + wave;
   if (row >= rows) return;
   if (seed_hbm) seed = *seed_hbm;
-  const int best_j = sample_row<T>(logits + static_cast<size_t>(row) * ldl, K, mask_id, x_t[row], seed, row0 + static_cast<uint32_t>(row), greedy, pc,
-                                   nullptr, lane, 0u);
+  const int best_j = (K == 1025 && mask_id < 1024)
+      ? sample_row_1025<T>(logits + static_cast<size_t>(row) * ldl, mask_id, x_t[row], seed, row0 + static_cast<uint32_t>(row), greedy, pc, lane, 0u)
+      : sample_row<T>(logits + static_cast<size_t>(row) * ldl, K, mask_id, x_t[row], seed, row0 + static_cast<uint32_t>(row), greedy, pc, nullptr, lane, 0u);
   if (lane == 0) {
     x_next[row] = best_j;
     if (x_next2) x_next2[row] = best_j;

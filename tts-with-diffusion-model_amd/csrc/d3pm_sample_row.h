@@ -93,5 +93,94 @@ __device__ __forceinline__ int sample_row(P lr, int K, int mask_id, int x, uint6
   return best_j;
 }
 
+// The same routine for n_classes = 1025 = 4 x 256 + 1 (1024 codec ids + the mask id: every model of the reference, ar_discrete.py:255)
+// without a predicate in it.  The general routine above walks five passes of 64 groups x 4 classes and tests every group and every
+// class against K -- 121 exec-mask branches in the compiled kernel, and a fifth pass that exists for ONE class (1024, lane 0).
+// Here passes 0..3 cover classes 0..1023 unconditionally and class 1024 is a tail element of lane 0 (the other lanes carry a -inf
+// logit, whose exp is 0: what they added in the general routine as well).  Every operation on a class, the order in which a lane
+// accumulates its partial sums (ascending class, the tail last) and the first-index argmax are those of sample_row: same bits.
+template <typename T, typename P>
+__device__ __forceinline__ int sample_row_1025(P lr, int mask_id, int x, uint64_t seed, uint32_t grow, int greedy,
+                                               const PosteriorConsts& pc, int lane, uint32_t stream = 0u) {
+  constexpr int K = 1025;
+  float z[4][4], zt;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      z[i][w] = rn16(static_cast<float>(lr[(lane + i * kWave) * 4 + w]));
+      mx = fmaxf(mx, z[i][w]);
+    }
+  zt = lane == 0 ? rn16(static_cast<float>(lr[K - 1])) : -INFINITY;
+  mx = fmaxf(mx, zt);
+  int best_j = 0;
+  float best_v = -INFINITY;
+  if (pc.t == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (z[i][w] > best_v) { best_v = z[i][w]; best_j = (lane + i * kWave) * 4 + w; }
+    if (zt > best_v) { best_v = zt; best_j = K - 1; }
+  } else {
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        z[i][w] = expf(z[i][w] - mx);
+        sum += z[i][w];
+      }
+    zt = expf(zt - mx);
+    sum += zt;
+    sum = wave_sum(sum);
+    float s_other = 0.f, p_mask = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float p = rn16(z[i][w] / sum);
+        z[i][w] = p;
+        const bool is_mask = (lane + i * kWave) * 4 + w == mask_id;
+        p_mask = is_mask ? p : p_mask;
+        s_other += is_mask ? 0.f : p;           // (+ 0 leaves the partial sum as it is: the general routine skips the add)
+      }
+    zt = rn16(zt / sum);
+    s_other += zt;                              // class 1024 is never the mask id (512)
+    s_other = wave_sum(s_other);
+    p_mask = wave_sum(p_mask);
+    const float f2_mask = rn16(fmaf(s_other, pc.cbar_prev, p_mask));
+    const bool x_is_mask = (x == mask_id);
+    auto one = [&](int j, float p, float u) __attribute__((always_inline)) {
+      const float lf1 = x_is_mask ? (j == mask_id ? pc.log_f1_one : pc.log_f1_c) : (j == x ? pc.log_f1_d : pc.log_f1_zero);
+      const float f2 = (j == mask_id) ? f2_mask : rn16(p * pc.dbar_prev);
+      const float lf2 = rn16(logf(rn16(f2 + kEps)));
+      const float out = rn16(lf1 + lf2);
+      return greedy ? out : out + gumbel(u);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = lane + i * kWave;
+      float u[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+      if (!greedy) noise4(seed, static_cast<uint32_t>(g), grow, static_cast<uint32_t>(pc.t), stream, u);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float v = one(g * 4 + w, z[i][w], u[w]);
+        if (v > best_v) { best_v = v; best_j = g * 4 + w; }   // ascending j per lane keeps the first maximum
+      }
+    }
+    {
+      float u[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+      if (!greedy) noise4(seed, 256u, grow, static_cast<uint32_t>(pc.t), stream, u);      // group 256 = classes 1024..1027: word 0
+      const float v = one(K - 1, zt, u[0]);
+      if (lane == 0 && v > best_v) { best_v = v; best_j = K - 1; }
+    }
+  }
+  wave_argmax(best_v, best_j);
+  return best_j;
+}
+
 }  // namespace
 }  // namespace d3pm
