@@ -152,3 +152,32 @@ def test_denoiser_folded_vs_unfolded_and_shard_invariance(built_lib, dtype, tol)
     # ... and without the hint the shard runs the small-batch attention kernels: rounding-level differences, not equality
     lg_n = smp.denoise(x[sl].contiguous(), fm, t, kv_ts, kv_ps)[0]
     assert (lg_n.float() - lg_f[sl].float()).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_loop_equals_step_by_step_ops_and_the_general_sampler(built_lib, dtype):
+    """Inside d3pm_sample_loop the sampler launch of iteration t also prepares iteration t - 1 (embedding rows + their moments, fc1
+    under norm3 + FiLM(t - 1): posterior_sample_prep_rows), and for 1025 classes the row routine is the predicate-free one
+    (sample_row_1025).  Both must be invisible: the loop's trace equals a chain of d3pm_denoise_step + d3pm_posterior_sample calls
+    (stand-alone embedding / fold launches), and the ids of the specialised routine equal those of the general routine (taken when
+    the posterior is asked for) on the same logits."""
+    from vall_e.vall_e import AR, synth
+    cfg = synth.D3PMConfig.libritts()
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0))
+    m = m.to(dtype).to(DEV)
+    smp = m.sampler()
+    texts, proms = synth.make_inputs(cfg, 3, 1)
+    ct, cp = m.encode_conditions(texts, proms)
+    kv_t, kv_p = smp.cond_kv(ct, cp)
+    x, fm = m.canvas_init(3)
+    xs = x.clone()
+    trace = smp.sample_loop(x, fm, 99, 92, kv_t, kv_p, seed=77, trace=True)
+    for i, t in enumerate(range(99, 92, -1)):
+        lg, _ = smp.denoise(xs, fm, t, kv_t, kv_p)
+        nxt, _ = smp.posterior_sample(lg, xs, t, seed=77)
+        nxt_general, post = smp.posterior_sample(lg, xs, t, seed=77, want_posterior=True)
+        assert torch.equal(nxt, nxt_general), f"t={t}: the 1025-class routine and the general routine draw different ids"
+        assert torch.equal(trace[i], nxt), f"t={t}: the loop (fused preparation) and the step-by-step ops disagree on {(trace[i] != nxt).sum().item()} ids"
+        xs = nxt
+    assert torch.equal(x, xs)
