@@ -77,10 +77,11 @@ enum {
  * agree to rounding noise, not bit for bit: the attention instruction shape (attn_query_groups 32 / 33, attn_cross_resident 4 / 5,
  * and -- in auto mode -- the batch regime, see regime_batch) and ln_fold.  Within one setting of those a result never depends on
  * the batch an utterance rides in, nor on how a batch is split over ranks or streams.
- *   gemm_variant       0 = auto (default): big-tile persistent schedule (192 x 256 or 96 x 512 tiles, eight waves, one workgroup
- *                          per CU) when the shape divides into >= 200 such tiles that fill whole rounds of the 256 CUs, else the
- *                          latency schedule (64 x 64 tiles, whole-K operand panels in flight) for M <= 1536 rows, the 128 x 128
- *                          throughput schedule otherwise;
+ *   gemm_variant       0 = auto (default): the big-tile persistent schedule when the shape divides into whole tiles that fill >= 85 %
+ *                          of their rounds over the CUs -- 192 x 128 tiles (four waves, two workgroups per CU) first, then 192 x 256,
+ *                          then 96 x 512 (eight waves, one workgroup per CU); 192 x 128 also for mid-size batches that give at
+ *                          least every (long K: every second) CU a tile; else the latency schedule (64 x 64 tiles, whole-K operand
+ *                          panels in flight) for M <= 1536 rows, the 128 x 128 throughput schedule otherwise;
  *                      2 = always the throughput schedule (one LDS stage, 4 workgroups per CU; persistent over the 128 x 128
  *                          tiles when M and N are multiples of 128 and there are >= 512 tiles, else as 5);
  *                      3 = always the round-1 latency schedule (128 x 128 tiles, two stages, asm DMA prefetch);

@@ -8,12 +8,13 @@
 // Why a second structure.  With K = d_model = 512 the 128 x 128 kernels of d3pm_mfma_gemm.hip move one byte from L2
 // into LDS per 64 flop; the measured L2 -> LDS rate of a CU (~32 B/clk) then caps them at half the MFMA rate
 // (profiles/round1_*: 577 .. 853 TFLOP/s by shape, 0.30 of peak over the loop).  The lever is bytes per flop:
-//   * one workgroup of EIGHT waves per CU owns a 192 x 256 (or 96 x 512) output tile -- 110 (81) flop per staged
-//     byte -- and each wave a 96 x 64 sub-tile (6 x 4 MFMA tiles of 16 x 16, 96 accumulator registers);
-//   * the tile shapes divide the bench workload exactly: M = 32 utterances x 768 rows = 128 x 192 rows, N = 512 /
-//     1536 / 2048 = 2 / 6 / 8 x 256 columns, so every projection is a whole number of rounds over the 256 CUs
-//     (256 / 512 / 768 / 1024 tiles) -- the 128 x 128 / 256 x 256 grids left a quarter of the chip idle in the last
-//     round;
+//   * a wave owns a 96 x 64 sub-tile (6 x 4 MFMA tiles of 16 x 16, 96 accumulator registers); a workgroup is 2 x 2 of them (192 x 128,
+//     77 flop per staged byte, TWO workgroups per CU: the default since round 3 -- in the sampler's loop two independent
+//     workgroups hide cold operands and each other's epilogue better than one, big_linear_tile below) or eight (192 x 256 / 96 x 512,
+//     110 / 81 flop per staged byte, one workgroup per CU);
+//   * the tile shapes divide the bench workload exactly: M = 32 utterances x 750 rows = 125 x 192 rows, N = 512 / 1024 / 1536 /
+//     2048 = 4 / 8 / 12 / 16 x 128 columns, i.e. 500 / 1000 / 1500 / 2000 tiles over 512 resident workgroups (0.98 / 1.95 / 2.93 /
+//     3.9 rounds) -- the 128 x 128 / 256 x 256 grids left a quarter of the chip idle in the last round (DESIGN_HISTORY.md section 3);
 //   * two LDS stages of (TM + TN) x 128 B; the next k-step's 1-KiB DMA pieces (global_load_lds_dwordx4 from inline
 //     asm, invisible to hipcc's wait counters) are issued one per four MFMAs inside the current k-step, so the
 //     memory pipeline's issue back-pressure hides under the partner wave's MFMAs; one s_barrier per k-step with a
