@@ -181,3 +181,49 @@ def test_loop_equals_step_by_step_ops_and_the_general_sampler(built_lib, dtype):
         assert torch.equal(trace[i], nxt), f"t={t}: the loop (fused preparation) and the step-by-step ops disagree on {(trace[i] != nxt).sum().item()} ids"
         xs = nxt
     assert torch.equal(x, xs)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_sampler_early_out_on_revealed_rows_returns_the_full_routines_ids(built_lib, dtype):
+    """sample_row_1025 returns the kept token of a revealed row (x_t != mask) without the per-class posterior when that token's exact
+    score clears an upper bound of every other class's (d3pm_sample_row.h).  The ids must be those of the full routine -- taken by the
+    general sample_row when the posterior is asked for -- on every kind of row: mostly masked (t = 99), half revealed, almost all
+    revealed, and on logits made hostile to the test (peaked on ANOTHER class than the kept one, so that the kept token loses the race
+    and the fallback has to run; flat; peaked on the kept token)."""
+    from vall_e.vall_e import AR, synth
+    cfg = synth.D3PMConfig.libritts()
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0))
+    m = m.to(dtype).to(DEV)
+    smp = m.sampler()
+    B = 4
+    texts, proms = synth.make_inputs(cfg, B, 1)
+    ct, cp = m.encode_conditions(texts, proms)
+    kv_t, kv_p = smp.cond_kv(ct, cp)
+    x, fm = m.canvas_init(B)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rows, K = x.numel(), 1025
+    n_revealed_total, n_changed_total, t_prev = 0, 0, 99
+    for t in (99, 60, 30, 10, 2):
+        if t != 99:                      # advance the canvas of the previous case to x_t along the build's own trajectory
+            smp.sample_loop(x, fm, t_prev, t, kv_t, kv_p, seed=11 + t)
+        t_prev = t
+        xs = x.clone()
+        lg, _ = smp.denoise(xs, fm, t, kv_t, kv_p)
+        variants = [lg]
+        flat = lg.reshape(rows, K).float()
+        kept = xs.reshape(rows).long().clamp(max=K - 1)
+        other = (kept + 17) % 1024
+        peaked_other = flat.clone(); peaked_other[torch.arange(rows), other] += 12.0
+        peaked_kept = flat.clone(); peaked_kept[torch.arange(rows), kept] += 12.0
+        variants += [peaked_other.to(dtype).reshape(lg.shape), peaked_kept.to(dtype).reshape(lg.shape), torch.zeros_like(lg),
+                     (flat * 6.0).to(dtype).reshape(lg.shape)]
+        for vi, logits in enumerate(variants):
+            fast, _ = smp.posterior_sample(logits, xs, t, seed=1000 + t)
+            full, _ = smp.posterior_sample(logits, xs, t, seed=1000 + t, want_posterior=True)
+            assert torch.equal(fast, full), f"t={t} variant {vi}: {(fast != full).sum().item()} ids differ between the early-out and the full routine"
+            revealed = xs.reshape(-1) != cfg.mask_id
+            n_revealed_total += int(revealed.sum())
+            n_changed_total += int((full.reshape(-1)[revealed] != xs.reshape(-1)[revealed]).sum())
+    assert n_revealed_total > 10000, "the cases must contain revealed rows"
+    assert n_changed_total > 100, "and rows whose kept token loses the race (the fallback path)"
