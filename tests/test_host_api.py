@@ -230,3 +230,22 @@ def test_nar_grid_is_padded_to_whole_gemm_tiles_only_when_cheap():
         assert t_max(32, 50, 225, 750) == 1027
     finally:
         NAR.pad_rows_to_tiles = True
+
+
+def test_kernels_with_asynchronous_asm_loads_do_not_spill():
+    """gemm_mfma_big's folded-LayerNorm instantiations (EPI_LNF = 64) request the row moments and the per-column vectors with
+    `global_load_dword*` from inline asm and wait for them by hand (counted vmcnt), because hipcc would otherwise drain the DMA
+    stream in front of every use.  hipcc believes the destination registers are valid as soon as the asm statement has been
+    issued: if it ever SPILLS one of them it stores the stale register and the load later lands in a register that holds
+    something else -- an address, say.  A round-4 experiment that pushed those kernels to 256 registers + 28 bytes of scratch
+    ended in a memory access fault on the GPU.  So: those instantiations must compile without scratch (cross-compiles, no GPU)."""
+    import subprocess
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh"), "d3pm_mfma_gemm_big.hip"],
+                         capture_output=True, text=True, timeout=900).stdout
+    rows = [l for l in out.splitlines() if "gemm_mfma_big" in l]
+    assert len(rows) >= 40, out[-2000:]
+    lnf = [l for l in rows if re.search(r"gemm_mfma_bigID(F16_|F16b)Li(64|65)E", l)]
+    assert len(lnf) >= 6, "the LNF / LNF + GELU instantiations of three geometries and two dtypes"
+    for l in lnf:
+        m = re.search(r"VGPR\s+(\d+).*scratch\s+(\d+)", l)
+        assert m and int(m.group(2)) == 0 and int(m.group(1)) <= 256, f"spilling kernel with asynchronous asm loads: {l}"
