@@ -227,3 +227,27 @@ def test_sampler_early_out_on_revealed_rows_returns_the_full_routines_ids(built_
             n_changed_total += int((full.reshape(-1)[revealed] != xs.reshape(-1)[revealed]).sum())
     assert n_revealed_total > 10000, "the cases must contain revealed rows"
     assert n_changed_total > 100, "and rows whose kept token loses the race (the fallback path)"
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2.5e-2), (torch.bfloat16, 1.5e-1)])
+def test_condition_encoders_at_d512_on_padded_heads_track_the_torch_modules(built_lib, dtype, tol):
+    """At d_model = 512 the encoders' 16 heads are 32 wide; since round 4 their self-attention runs on the 64-wide MFMA kernels
+    through zero-padded heads (csrc/d3pm_headpad.hip) instead of the generic FMA kernel.  The conditions must track the torch modules
+    of the same weights and dtype (the eager path the generic kernel mirrors) as closely as 16-bit rounding allows, for both
+    encoders, at batch 1 and at batch 3 with the utterances of a batch equal to their batch-1 runs."""
+    from vall_e.vall_e import AR, synth
+    cfg = synth.D3PMConfig.libritts()
+    m = AR.from_config(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 0))
+    m = m.to(dtype).to(DEV)
+    texts, proms = synth.make_inputs(cfg, 3, 1)
+    ct, cp = m.encode_conditions(texts, proms)
+    rt, rp = m.encode_conditions_torch(texts, proms)
+    for name, a, b in (("text", ct, rt), ("prompt", cp, rp)):
+        a, b = a.float().cpu(), b.float().cpu()
+        err = (a - b).abs().max().item()
+        scale = b.abs().max().item()
+        assert torch.isfinite(a).all() and err < tol * max(scale, 1.0), (name, err, scale)
+    for b_ in range(3):
+        ct1, cp1 = m.encode_conditions(texts[b_:b_ + 1], proms[b_:b_ + 1])
+        assert torch.equal(ct1[0], ct[b_]) and torch.equal(cp1[0], cp[b_]), f"utterance {b_}: the conditions depend on the batch"

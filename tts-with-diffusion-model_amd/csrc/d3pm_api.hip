@@ -708,7 +708,14 @@ int d3pm_cond_kv(const d3pm_shape* sh, const d3pm_weights* w, int batch, const v
 }
 
 // ---- condition encoders ----------------------------------------------------------------------------
-struct CondWs { char *x, *tmp, *qkv, *att, *ff; size_t total; };
+struct CondWs { char *x, *tmp, *qkv, *att, *ff, *qkv_pad, *att_pad; size_t total; };
+#ifndef D3PM_ENC_HEAD_PAD
+#define D3PM_ENC_HEAD_PAD 1      // A/B builds (tools/build_variant.py): 0 = the encoders' 32-wide heads stay on the generic attention kernel
+#endif
+// the encoder's self-attention on the 64-wide MFMA kernels through zero-padded heads (d3pm_headpad.hip)
+static bool encoder_pads_heads(const d3pm_shape& sh, const d3pm_encoder_weights& e) {
+  return D3PM_ENC_HEAD_PAD != 0 && (sh.dtype == D3PM_F16 || sh.dtype == D3PM_BF16) && e.n_heads > 0 && sh.d_model == 32 * e.n_heads;
+}
 static CondWs carve_cond(const d3pm_shape& sh, const d3pm_cond_weights& cw, int batch, char* base) {
   const size_t es = dtype_size(sh.dtype), d = sh.d_model;
   const size_t n = static_cast<size_t>(batch) * (sh.s_prompt > sh.s_text ? sh.s_prompt : sh.s_text);
@@ -722,6 +729,10 @@ static CondWs carve_cond(const d3pm_shape& sh, const d3pm_cond_weights& cw, int 
   w.qkv = take(n * 3 * d * es);
   w.att = take(n * d * es);
   w.ff = take(n * ffw * es);
+  if (encoder_pads_heads(sh, cw.text_encoder) || encoder_pads_heads(sh, cw.prompt_encoder)) {
+    w.qkv_pad = take(n * 6 * d * es);
+    w.att_pad = take(n * 2 * d * es);
+  }
   w.total = off;
   return w;
 }
@@ -740,7 +751,16 @@ static int run_encoder(const d3pm_shape& sh, const d3pm_encoder_weights& e, int 
     AttnArgs a;
     a.Q = ws.qkv; a.ldq = 3 * d; a.K = at(ws.qkv, d, es); a.V = at(ws.qkv, 2 * d, es); a.ldkv = 3 * d; a.O = ws.att; a.ldo = d;
     a.B = batch; a.Tq = seq; a.S = seq; a.H = e.n_heads; a.hd = hd; a.scale = static_cast<float>(std::sqrt(1.0 / hd));
-    D3PM_TRY(run_attention(cx, dt, a, 0, s));
+    if (encoder_pads_heads(sh, e) && ws.qkv_pad) {
+      D3PM_TRY(pad_heads(ws.qkv, ws.qkv_pad, n, 3 * e.n_heads, hd, s));
+      AttnArgs p = a;
+      p.Q = ws.qkv_pad; p.K = at(ws.qkv_pad, 2 * d, es); p.V = at(ws.qkv_pad, 4 * d, es); p.ldq = p.ldkv = 6 * d;
+      p.O = ws.att_pad; p.ldo = 2 * d; p.hd = 2 * hd;                // scale stays 1 / sqrt(hd)
+      D3PM_TRY(run_attention(cx, dt, p, 0, s));
+      D3PM_TRY(unpad_heads(ws.att_pad, ws.att, n, e.n_heads, hd, s));
+    } else {
+      D3PM_TRY(run_attention(cx, dt, a, 0, s));
+    }
     g = LinearArgs();   // x + self_attn(x), then post-norm
     g.X = ws.att; g.ldx = d; g.W = w.out_w; g.bias = w.out_b; g.Y = ws.tmp; g.ldy = d; g.R1 = ws.x; g.ldr = d; g.M = n; g.N = d; g.K = d;
     D3PM_TRY(run_linear(cx, dt, g, 0, s));

@@ -143,6 +143,9 @@ int generic_attention(int dtype, const AttnArgs& a, hipStream_t s);
 int generic_layernorm(int dtype, const LayerNormArgs& a, hipStream_t s);
 int embed_tokens(int dtype, const EmbedArgs& a, hipStream_t s);
 // condition-side embeddings: text rows = rn(W[tok] + pe0); prompt rows = rn(rn(sum_l W[l][tok_l]) + pe[s])
+// head_dim hd -> 2 hd re-layout around an attention call (d3pm_headpad.hip): [rows][groups][hd] <-> [rows][groups][2 hd], zeros above
+int pad_heads(const void* in, void* out, long long rows, int groups, int hd, hipStream_t s);
+int unpad_heads(const void* in, void* out, long long rows, int groups, int hd, hipStream_t s);
 int cond_embed_text(int dtype, const int32_t* tok, const void* table, const void* pe0, void* y, int rows, int d,
                     int n_classes, hipStream_t s);
 int cond_embed_prompt(int dtype, const int32_t* codes, int n_levels, const void* tables, const void* pe, void* y,
