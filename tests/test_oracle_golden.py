@@ -244,3 +244,24 @@ def test_n_q_extension_oracle_reduces_to_the_pinned_oracle_at_n_q_1():
     with torch.no_grad():
         cp, ct = orc.conditions(texts[0], proms[0])
         assert torch.equal(NQ.logits(sd, shape, x[:, None], 50, cp, ct, mask)[:, 0], orc.logits(x, 50, cp, ct, mask))
+
+
+
+def test_wide_trajectory_fixture_is_the_oracles_and_ends_on_the_references_ids():
+    """tests/golden/wide_f16_trajectory.npz (make_wide_trajectory.py) is what the GPU suite teacher-forces the HIP path along: it
+    must be the oracle's current d = 512 fp16 loop row by row, and end on the ids the reference produced (wide_step.npz)."""
+    from vall_e.vall_e import synth
+    cfg = synth.D3PMConfig(d_model=512, n_heads=8, n_layers=6)
+    sd32 = synth.make_state_dict(cfg, 0)
+    texts, proms = synth.make_inputs(cfg, 1, 1)
+    fx = load("wide_f16_trajectory.npz")
+    ref_final = load("wide_step.npz")["loop_seed123"].astype(np.int64)
+    assert np.array_equal(fx["x_0"].astype(np.int64), ref_final)
+    orc = O.Oracle({k: v.half() for k, v in sd32.items()}, O.Shape.of(cfg))
+    trace = []
+    with torch.no_grad():
+        end = orc.generate(texts[0], proms[0], O.philox_noise(123, cfg.canvas), trace=trace)
+    assert np.array_equal(end.numpy(), ref_final)
+    assert len(trace) == fx["x"].shape[0] == 99
+    for i, row in enumerate(trace):
+        assert np.array_equal(row.numpy(), fx["x"][i].astype(np.int64)), f"row {i} of the fixture is not the oracle's"
