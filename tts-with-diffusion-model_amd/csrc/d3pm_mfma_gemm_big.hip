@@ -12,9 +12,10 @@
 //     77 flop per staged byte, TWO workgroups per CU: the default since round 3 -- in the sampler's loop two independent
 //     workgroups hide cold operands and each other's epilogue better than one, big_linear_tile below) or eight (192 x 256 / 96 x 512,
 //     110 / 81 flop per staged byte, one workgroup per CU);
-//   * the tile shapes divide the bench workload exactly: M = 32 utterances x 750 rows = 125 x 192 rows, N = 512 / 1024 / 1536 /
-//     2048 = 4 / 8 / 12 / 16 x 128 columns, i.e. 500 / 1000 / 1500 / 2000 tiles over 512 resident workgroups (0.98 / 1.95 / 2.93 /
-//     3.9 rounds) -- the 128 x 128 / 256 x 256 grids left a quarter of the chip idle in the last round (DESIGN_HISTORY.md section 3);
+//   * the tile shapes divide the bench workload exactly: M = 32 utterances x 768 canvas rows = 128 x 192 rows, N = 512 / 1024 /
+//     1536 / 2048 = 4 / 8 / 12 / 16 x 128 columns, i.e. 512 / 1024 / 1536 / 2048 tiles = 1 / 2 / 3 / 4 whole rounds over the 512
+//     resident workgroups -- the 128 x 128 / 256 x 256 grids left a quarter of the chip idle in the last round (DESIGN_HISTORY.md
+//     section 3);
 //   * two LDS stages of (TM + TN) x 128 B; the next k-step's 1-KiB DMA pieces (global_load_lds_dwordx4 from inline
 //     asm, invisible to hipcc's wait counters) are issued one per four MFMAs inside the current k-step, so the
 //     memory pipeline's issue back-pressure hides under the partner wave's MFMAs; one s_barrier per k-step with a
